@@ -1,0 +1,299 @@
+/*
+ * irf.h — C ABI of the MI355X-native IRFinder read-block counting engine.
+ *
+ * This is the drop-in boundary (SURVEY.md §8 b).  Upstream IRFinder has no FFI
+ * for this path: the boundary there is the C++ interface
+ *
+ *     class ReadBlockProcessor {
+ *         virtual void ProcessBlocks(const FragmentBlocks&) = 0;
+ *         virtual void ChrMapUpdate(const std::vector<std::string>&) = 0;
+ *     };
+ *
+ * (⟨upstream⟩ src/irfinder/ReadBlockProcessor.h — the source is NOT in
+ * /root/reference, which holds only README.md:1-7; every "replaces" note
+ * below therefore cites the upstream file by name, without line numbers.
+ * See SURVEY.md §0.)  The C++ adapter that implements that interface on top
+ * of this ABI is irfinder_amd/host/hip_block_processor.h.
+ *
+ * Conventions: every function returns 0 on success, a negative irf_status on
+ * failure; no exception crosses the ABI; irf_last_error() gives the text.
+ * A context is thread-compatible (one host thread per context), not thread-safe.
+ * Coordinates are 0-based half-open (BAM).  Strand index: [0] = neg, [1] = pos.
+ */
+#ifndef IRF_H
+#define IRF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRF_ABI_VERSION 1
+
+typedef enum irf_status {
+    IRF_OK = 0,
+    IRF_E_ARG = -1,      /* bad argument / NULL / inconsistent sizes          */
+    IRF_E_PARSE = -2,    /* malformed reference file or BAM stream             */
+    IRF_E_RANGE = -3,    /* value outside what the packed device layout holds  */
+    IRF_E_STATE = -4,    /* call out of order (e.g. submit before chr map)     */
+    IRF_E_DEVICE = -5,   /* HIP runtime error / no device                      */
+    IRF_E_NOMEM = -6,
+    IRF_E_IO = -7
+} irf_status;
+
+/* Every recalled-behaviour uncertainty of SURVEY.md App. B.5 (OQ-n) is one
+ * field here; defaults (irf_params_default) are the survey's stated guesses. */
+typedef struct irf_params {
+    uint32_t struct_size;           /* = sizeof(irf_params), ABI check          */
+    /* ---- reader (BAM2blocks) ---- */
+    uint32_t skip_flag_mask;        /* OQ-2  records with any of these flag bits are skipped (0x4) */
+    uint32_t pair_long_inclusive;   /* OQ-1  0: Long iff e1 <  pos2 ; 1: e1 <= pos2               */
+    uint32_t pair_short_inclusive;  /* OQ-1  1: Short iff e1 >= e2  ; 0: e1 >  e2                 */
+    /* ---- counters ---- */
+    uint32_t junc_min_flank;        /* OQ-4  both flanking blocks >= this (5)                      */
+    uint32_t sp_overhang_left;      /* SpansPoint::setSpanLength(5,4)                              */
+    uint32_t sp_overhang_right;
+    uint32_t sp_inclusive;          /* OQ-6  0: bs+L < p < be-R ; 1: bs+L <= p <= be-R             */
+    /* ---- per-intron statistics ---- */
+    uint32_t trim_centre_pct;       /* OQ-8  trimmed mean keeps the centre 40 %                    */
+    uint32_t pct_interpolate;       /* OQ-7  1: (N+1)p/100 with linear interpolation; 0: no interp */
+    uint32_t flank_offset;          /* OQ-9  first/last window starts 5 nt inside the intron       */
+    uint32_t flank_len;             /* OQ-9  ... and is 50 nt long                                 */
+    uint32_t flank_use_measured;    /* OQ-9  1: window ∩ measured blocks ; 0: raw coordinates      */
+    /* ---- directionality vote ---- */
+    uint32_t dir_ratio;             /* OQ-5  same > ratio*opp => +1, opp > ratio*same => -1 (10)   */
+    /* ---- output ---- */
+    uint32_t out_precision;         /* OQ-13 significant digits of doubles in the text files (6)   */
+    /* ---- warnings (OQ-12) ---- */
+    double warn_lowcover_min;       /* LowCover   if SpliceExact + IntronDepth < 10                */
+    double warn_lowsplice_min;      /* LowSplicing if SpliceExact < 4                              */
+    double warn_minor_ratio;        /* MinorIsoform if SpliceExact*1.33 < max(SpliceL,SpliceR)     */
+    double warn_nonuniform_rel;     /* NonUniformIntronCover if max flank > depth*1.5 + 4          */
+    double warn_nonuniform_abs;
+    /* ---- engine sizing (no upstream counterpart) ---- */
+    uint64_t junc_event_capacity;   /* device junction-event buffer, in events, before compaction  */
+    uint32_t keep_depth;            /* 1: keep whole-chromosome depth after finalize (FragmentsMap)*/
+    uint32_t reserved;
+} irf_params;
+
+void irf_params_default(irf_params* p);
+
+/* ------------------------------------------------------------------------ */
+/* Reference tables.  Replaces JunctionCount::loadRef, SpansPoint::loadRef,
+ * FragmentsInROI::loadRef (⟨upstream⟩ ReadBlockProcessor.cpp) and
+ * CoverageBlocks::loadRef (⟨upstream⟩ ReadBlockProcessor_CoverageBlocks.cpp). */
+typedef struct irf_ref irf_ref;
+
+int irf_ref_load_files(const char* ref_cover_bed, const char* ref_sj_ref,
+                       const char* ref_read_continues_ref, const char* ref_roi_bed,
+                       irf_ref** out, char* errbuf, size_t errbuf_len);
+/* Same, from memory.  Order of bufs: cover, sj, read-continues, ROI.        */
+int irf_ref_load_mem(const char* const bufs[4], const size_t lens[4],
+                     irf_ref** out, char* errbuf, size_t errbuf_len);
+void irf_ref_free(irf_ref* ref);
+uint32_t irf_ref_n_intron(const irf_ref* ref);
+uint32_t irf_ref_n_junction(const irf_ref* ref);
+uint32_t irf_ref_n_point(const irf_ref* ref);
+uint32_t irf_ref_n_roi(const irf_ref* ref);
+
+/* ------------------------------------------------------------------------ */
+/* One batch of fragments, structure-of-arrays.  One entry of the frag_*
+ * arrays is one upstream FragmentBlocks (⟨upstream⟩ FragmentBlocks.h) as it
+ * is handed to ProcessBlocks; blocks of fragment i are
+ * [frag_blk_off[i], frag_blk_off[i+1]) of the blk_* arrays, read 0 first.    */
+typedef struct irf_batch {
+    uint32_t n_frag;
+    uint32_t n_blk;
+    const uint32_t* frag_chr;      /* BAM refID (FragmentBlocks::chr_id)                     */
+    const uint8_t*  frag_flags;    /* bit0 direction (1 = +), bit1 readCount == 2            */
+    const uint32_t* frag_start;    /* readStart[0]                                           */
+    const uint32_t* frag_end;      /* readCount==2 ? max(readEnd[0],readEnd[1]) : readEnd[0] */
+    const uint32_t* frag_blk_off;  /* n_frag + 1 entries                                     */
+    const uint32_t* blk_start;     /* absolute: readStart[r] + rStarts[r][j]                 */
+    const uint32_t* blk_len;       /* rLens[r][j]                                            */
+    const uint8_t*  blk_read;      /* r: 0 or 1 (junctions are only within one read)         */
+    uint32_t mem_kind;             /* IRF_MEM_HOST or IRF_MEM_DEVICE                         */
+    uint32_t reserved;
+} irf_batch;
+
+#define IRF_MEM_HOST   0u   /* pageable or pinned host memory (pinned => async copy) */
+#define IRF_MEM_DEVICE 1u   /* already resident on the context's device              */
+
+#define IRF_FRAG_DIR   0x1u
+#define IRF_FRAG_TWO   0x2u
+
+typedef enum irf_warning {
+    IRF_WARN_NONE = 0,          /* "-" */
+    IRF_WARN_LOWCOVER = 1,
+    IRF_WARN_LOWSPLICING = 2,
+    IRF_WARN_MINORISOFORM = 3,
+    IRF_WARN_NONUNIFORM = 4
+} irf_warning;
+
+/* One IRFinder-IR-{nondir,dir}.txt table as columns; rows are the records of
+ * ref-cover.bed in file order.  Replaces the per-row computation of
+ * CoverageBlocksIRFinder::WriteOutput (⟨upstream⟩
+ * ReadBlockProcessor_CoverageBlocks.cpp).                                    */
+typedef struct irf_ir_table {
+    const double* coverage;
+    const double* intron_depth;
+    const double* p25;
+    const double* p50;
+    const double* p75;
+    const double* first50;
+    const double* last50;
+    const double* irratio;
+    const uint32_t* sp_left;       /* ExonToIntronReadsLeft  */
+    const uint32_t* sp_right;      /* ExonToIntronReadsRight */
+    const uint32_t* splice_left;
+    const uint32_t* splice_right;
+    const uint32_t* splice_exact;
+    const uint8_t*  warning;       /* irf_warning */
+} irf_ir_table;
+
+typedef struct irf_results {
+    int32_t  directionality;       /* JunctionCount::Directional(): -1, 0, +1               */
+    uint32_t n_chr;                /* BAM references                                         */
+    const uint64_t* chr_cnt;       /* [n_chr][2]  FragmentsInChr, (neg,pos)                  */
+    uint32_t n_roi;
+    const uint64_t* roi_cnt;       /* [2][n_roi]  FragmentsInROI, ref-ROI.bed file order     */
+    uint32_t n_sp;
+    const uint32_t* sp_chr;        /* chromosome slot (irf_chr_name)                          */
+    const uint32_t* sp_pos;
+    const uint32_t* sp_cnt;        /* [2][n_sp]   SpansPoint, sorted by (slot,pos)           */
+    uint64_t n_junc;               /* known ∪ observed junctions, sorted (slot,left,right)   */
+    const uint32_t* junc_chr;
+    const uint32_t* junc_left;
+    const uint32_t* junc_right;
+    const uint32_t* junc_cnt;      /* [2][n_junc]                                            */
+    const uint8_t*  junc_refdir;   /* 0 unknown, 1 '-', 2 '+', 3 both                        */
+    uint32_t n_intron;
+    uint32_t has_dir;              /* dir table valid (directionality != 0)                  */
+    irf_ir_table nondir;
+    irf_ir_table dir;
+    uint64_t n_fragments;          /* fragments submitted                                    */
+    uint64_t n_blocks;
+    uint64_t n_junction_events;
+} irf_results;
+
+/* ------------------------------------------------------------------------ */
+typedef struct irf_ctx irf_ctx;
+
+/* Builds the engine for one device.  `ref` is copied; it may be freed after. */
+int irf_create(const irf_params* params, const irf_ref* ref, int device, irf_ctx** out);
+void irf_destroy(irf_ctx* ctx);
+const char* irf_last_error(const irf_ctx* ctx);
+
+/* Replaces ReadBlockProcessor::ChrMapUpdate for all five processors at once.
+ * `lens` are the l_ref values of the BAM header (the depth arrays need them).
+ * `owned` (may be NULL = all) marks the references this context counts:
+ * fragments on other references are ignored (chromosome sharding, §8 e).    */
+int irf_chr_map_update(irf_ctx* ctx, uint32_t n_chr, const char* const* names,
+                       const uint32_t* lens, const uint8_t* owned);
+
+/* Replaces n_frag calls of ReadBlockProcessor::ProcessBlocks on each of
+ * FragmentsInChr, FragmentsInROI, JunctionCount, SpansPoint, CoverageBlocks
+ * and FragmentsMap.  Asynchronous: host arrays must stay valid and unmodified
+ * until irf_wait(batch_id) returns.                                          */
+int irf_submit_batch(irf_ctx* ctx, const irf_batch* batch, uint64_t* batch_id);
+int irf_wait(irf_ctx* ctx, uint64_t batch_id);
+
+/* End of input: scan depth, per-intron statistics, junction sort-reduce,
+ * directionality vote, IR tables.  Results stay on the device until
+ * irf_get_results.  Replaces the end-of-run half of ⟨upstream⟩ irfinder.cpp
+ * main() up to (not including) the file writers.                             */
+int irf_finalize(irf_ctx* ctx);
+/* Host view of the results (pointers owned by ctx, valid until reset/destroy). */
+int irf_get_results(irf_ctx* ctx, irf_results* out);
+/* Chromosome slot -> name.  Slots 0..n_chr-1 are the BAM references, further
+ * slots are chromosomes that occur only in the reference tables.            */
+const char* irf_chr_name(const irf_ctx* ctx, uint32_t slot);
+uint32_t irf_n_chr_slots(const irf_ctx* ctx);
+
+/* Writes IRFinder-IR-nondir.txt, IRFinder-IR-dir.txt (if directional),
+ * IRFinder-JuncCount.txt, IRFinder-SpansPoint.txt, IRFinder-ChrCoverage.txt,
+ * IRFinder-ROI.txt into outdir.  Replaces the writers of ⟨upstream⟩
+ * irfinder.cpp main() and the WriteOutput methods.                           */
+int irf_write_outputs(irf_ctx* ctx, const char* outdir);
+
+/* FragmentsMap (north_star; SURVEY OQ-14): per-base depth of strand `dir`
+ * (0 neg, 1 pos, 2 both) over [start,end) of BAM reference `chr`, copied to
+ * host `out` (end-start uint32).  Needs params.keep_depth = 1.               */
+int irf_get_depth(irf_ctx* ctx, uint32_t chr, uint32_t start, uint32_t end,
+                  uint32_t dir, uint32_t* out);
+
+/* Zero all counters for the next sample; reference tables and chr map stay. */
+int irf_reset(irf_ctx* ctx);
+
+/* Device-resident result export for the multi-GPU gather (§8 e): copies one
+ * named column into caller-owned DEVICE memory (no host round trip).  `what`
+ * is an irf_column; returns the element count in *n (call with dst == NULL
+ * to query the size).                                                        */
+typedef enum irf_column {
+    IRF_COL_IR_NONDIR_F64 = 0,   /* [8][n_intron] doubles, order of irf_ir_table   */
+    IRF_COL_IR_NONDIR_U32 = 1,   /* [6][n_intron] uint32 (5 counts + warning)      */
+    IRF_COL_IR_DIR_F64 = 2,
+    IRF_COL_IR_DIR_U32 = 3,
+    IRF_COL_JUNC_KEYS = 4,       /* n_obs uint64 packed junction keys, sorted      */
+    IRF_COL_JUNC_COUNTS = 5,     /* n_obs uint32                                   */
+    IRF_COL_SP_CNT = 6,          /* [2][n_sp] uint32                               */
+    IRF_COL_ROI_CNT = 7,         /* [2][n_roi] uint32                              */
+    IRF_COL_CHR_CNT = 8          /* [n_chr][2] uint32                              */
+} irf_column;
+int irf_export_device(irf_ctx* ctx, uint32_t what, void* dst_device, uint64_t* n);
+
+/* Time (ms) the device spent in the named stage during the last
+ * submit/finalize cycle, measured with HIP events on the engine's stream.   */
+typedef struct irf_timing {
+    float count_ms;      /* sum over batches of the fused count kernel       */
+    float scan_ms;
+    float stats_ms;
+    float junction_ms;
+    float table_ms;
+    float total_finalize_ms;
+    uint32_t n_count_launches;
+    uint32_t reserved;
+} irf_timing;
+int irf_get_timing(irf_ctx* ctx, irf_timing* out);
+
+/* ------------------------------------------------------------------------ */
+/* Host reader.  Replaces BAM2blocks (⟨upstream⟩ BAM2blocks.cpp:
+ * readBamHeader, processAll, processPair, processSingle, cigar2block) for
+ * callers that do not bring their own.  Parses an uncompressed BAM stream
+ * (what `gzip -cd x.bam` yields) or BGZF, pairs adjacent records, assembles
+ * fragments and appends them to growable SoA arrays.                        */
+typedef struct irf_reader irf_reader;
+
+typedef struct irf_reader_stats {
+    uint64_t n_records, n_nucleotides;
+    uint64_t n_singles, n_pairs, n_pairs_short, n_pairs_intersect, n_pairs_long;
+    uint64_t n_skipped, n_error;
+} irf_reader_stats;
+
+int irf_reader_create(const irf_params* params, irf_reader** out);
+void irf_reader_destroy(irf_reader* r);
+const char* irf_reader_last_error(const irf_reader* r);
+/* Feed bytes (any chunking).  is_bgzf: 1 = BGZF-compressed, 0 = raw BAM.     */
+int irf_reader_feed(irf_reader* r, const uint8_t* data, size_t len, int is_bgzf);
+/* Header (valid once parsed): returns n_ref, or a negative status if the
+ * header is not complete yet.                                                */
+int irf_reader_header(const irf_reader* r, const char* const** names, const uint32_t** lens);
+/* Fragments assembled so far, as a host batch (pointers owned by the reader,
+ * invalidated by the next feed/clear).                                       */
+int irf_reader_batch(const irf_reader* r, irf_batch* out);
+void irf_reader_clear_batch(irf_reader* r);
+int irf_reader_finish(irf_reader* r);       /* EOF: flags a dangling mate     */
+int irf_reader_get_stats(const irf_reader* r, irf_reader_stats* out);
+
+/* Pure functions of the reader, exposed for parity tests.                   */
+/* cigar2block: BAM cigar words -> relative block starts/lengths.            */
+int irf_cigar2block(const uint32_t* cigar, uint32_t n_cigar,
+                    uint32_t* starts, uint32_t* lens, uint32_t cap,
+                    uint32_t* n_blocks, uint32_t* genome_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRF_H */
