@@ -1,0 +1,951 @@
+// engine.hip — irf_ctx: device state, batch staging on HIP streams, the
+// finalize pipeline and the C ABI of include/irf.h.
+//
+// Stands where ⟨upstream⟩ irfinder.cpp main() wires five ReadBlockProcessor
+// objects to BAM2blocks: here one context owns all counter state in HBM and
+// every ProcessBlocks call becomes one row of a structure-of-arrays batch.
+//
+// HBM layout (per context; G = sum over owned BAM references of len+1 rounded
+// up to 64):
+//   diff/depth  int32 [2 strands][G]      difference events, scanned in place
+//   junc_keys   uint64 [capacity] x2      packed junction events + sort buffer
+//   sp_pos/cnt, roi_*, chr_*              reference tables and their counters
+//   intron tables                         global coordinates of measured blocks
+//   staging     2 x batch arrays          double buffer for host batches
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/irf.h"
+#include "../host/ref_tables.h"
+#include "kernels.h"
+
+struct irf_ref {
+    irf::RefTables t;
+};
+
+namespace {
+
+using irf::RefTables;
+namespace dev = irf::dev;
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(IRF_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;      // elements
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    // grows (never shrinks); contents are NOT preserved
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+struct Staging {
+    DevBuf<uint32_t> frag_chr, frag_start, frag_end, frag_blk_off, blk_start, blk_len;
+    DevBuf<uint8_t> frag_flags, blk_read;
+    hipEvent_t copied = nullptr;     // H2D copies of the batch in this slot are done
+    hipEvent_t consumed = nullptr;   // count kernel that reads this slot is done
+    uint64_t batch_id = 0;
+    bool in_use = false;
+};
+
+}   // namespace
+
+struct irf_ctx {
+    irf_params P;
+    RefTables ref;
+    int device = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    std::string err;
+    bool have_map = false, finalized = false, results_ready = false;
+
+    // ---- chromosome map ----
+    uint32_t n_chr = 0;                          // BAM references
+    std::vector<std::string> slot_names;         // BAM references, then reference-only names (sorted)
+    std::vector<uint32_t> chr_len;
+    std::vector<uint8_t> chr_owned;
+    std::vector<uint64_t> chr_base;              // per BAM reference, offset inside a plane
+    std::vector<uint32_t> refchr_slot;           // reference chr id -> slot
+    uint64_t plane_stride = 0;
+
+    // ---- device state ----
+    DevBuf<int32_t> d_diff;
+    DevBuf<uint64_t> d_chr_base;
+    DevBuf<uint32_t> d_chr_len;
+    DevBuf<uint8_t> d_chr_owned;
+    DevBuf<uint32_t> d_chr_cnt;
+    DevBuf<uint32_t> d_roi_off, d_roi_start, d_roi_end, d_roi_idx, d_roi_cnt;
+    DevBuf<uint32_t> d_sp_off, d_sp_pos, d_sp_cnt;
+    DevBuf<uint64_t> d_junc_a, d_junc_b;
+    DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
+    DevBuf<uint32_t> d_err;
+    DevBuf<uint32_t> d_ws;                       // scan / radix workspace
+    DevBuf<uint32_t> d_flags, d_uidx, d_ustart, d_ucount;
+    DevBuf<uint64_t> d_ukeys;
+    uint64_t n_unique = 0, n_events = 0;
+    const uint64_t* d_sorted = nullptr;
+    // intron tables
+    DevBuf<uint8_t> d_in_valid, d_in_plus;
+    DevBuf<uint64_t> d_in_gstart, d_in_gend, d_blk_gstart, d_in_measured;
+    DevBuf<uint32_t> d_in_blk_off, d_blk_len;
+    DevBuf<int32_t> d_sp_idx_s, d_sp_idx_e, d_us_idx, d_ue_idx;
+    DevBuf<uint64_t> d_us_pos, d_ue_pos, d_known_keys;
+    DevBuf<uint8_t> d_known_dir;
+    DevBuf<uint32_t> d_left_cnt, d_right_cnt;
+    uint32_t n_us = 0, n_ue = 0, n_known_dev = 0;
+    DevBuf<double> d_out_f64[2];
+    DevBuf<uint32_t> d_out_u32[2];
+
+    // host-side permutations of the reference tables
+    uint32_t n_sp = 0, n_roi = 0, n_intron = 0;
+    std::vector<uint32_t> sp_slot, sp_pos_sorted;          // (slot,pos) order = device order
+    std::vector<uint32_t> kj_slot, kj_left, kj_right;      // known junctions sorted by (slot,left,right)
+    std::vector<uint8_t> kj_dir;
+
+    // ---- batches ----
+    Staging stage[2];
+    uint64_t next_batch_id = 1;
+    uint64_t n_fragments = 0, n_blocks = 0, junc_upper = 0;
+    int32_t directionality = 0;
+
+    // ---- timing ----
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> count_events;
+    size_t count_events_used = 0;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    irf_timing timing;
+
+    // ---- host results ----
+    std::vector<uint64_t> h_chr_cnt, h_roi_cnt;
+    std::vector<uint32_t> h_sp_chr, h_sp_pos, h_sp_cnt;
+    std::vector<uint32_t> h_j_chr, h_j_left, h_j_right, h_j_cnt;
+    std::vector<uint8_t> h_j_refdir;
+    std::vector<double> h_f64[2];
+    std::vector<uint32_t> h_u32[2];
+    std::vector<uint8_t> h_warn[2];
+
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+
+    int init();
+    void free_events();
+    int build_map(uint32_t n, const char* const* names, const uint32_t* lens, const uint8_t* owned);
+    int zero_counters();
+    dev::CountTables count_tables();
+    int ensure_junc_capacity(uint64_t need);
+    int submit(const irf_batch* b, uint64_t* id);
+    int wait(uint64_t id);
+    int finalize();
+    int fetch_results();
+};
+
+namespace {
+
+template <class T>
+int upload(irf_ctx* c, DevBuf<T>& buf, const std::vector<T>& v) {
+    hipError_t e = buf.reserve(v.size());
+    if (e != hipSuccess) return c->fail(IRF_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (!v.empty()) {
+        e = hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return c->fail(IRF_E_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        e = hipStreamSynchronize(c->stream);      // v may be a temporary
+        if (e != hipSuccess) return c->fail(IRF_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <class T>
+int alloc_zero(irf_ctx* c, DevBuf<T>& buf, size_t n) {
+    hipError_t e = buf.reserve(n);
+    if (e != hipSuccess) return c->fail(IRF_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (n) {
+        e = hipMemsetAsync(buf.p, 0, n * sizeof(T), c->stream);
+        if (e != hipSuccess) return c->fail(IRF_E_DEVICE, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+
+}   // namespace
+
+int irf_ctx::init() {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (auto& s : stage) {
+        HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    }
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    memset(&timing, 0, sizeof timing);
+    return 0;
+}
+
+void irf_ctx::free_events() {
+    for (auto& s : stage) {
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.consumed) (void)hipEventDestroy(s.consumed);
+        s.copied = s.consumed = nullptr;
+    }
+    for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& p : count_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    count_events.clear();
+    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+}
+
+// Replaces ChrMapUpdate of all processors: binds reference-table chromosomes to
+// BAM refIDs and lays every table out in device order.
+int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* lens, const uint8_t* owned) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipStreamSynchronize(copy_stream));
+    n_chr = n;
+    slot_names.clear();
+    chr_len.assign(lens, lens + n);
+    chr_owned.assign(n, 1);
+    if (owned) chr_owned.assign(owned, owned + n);
+    std::map<std::string, uint32_t> slot_of;
+    for (uint32_t i = 0; i < n; i++) {
+        slot_names.emplace_back(names[i]);
+        slot_of.emplace(slot_names.back(), i);        // first occurrence wins
+    }
+    {
+        std::vector<std::string> extra;
+        for (auto& nm : ref.chr_names) if (!slot_of.count(nm)) extra.push_back(nm);
+        std::sort(extra.begin(), extra.end());
+        for (auto& nm : extra) { slot_of.emplace(nm, (uint32_t)slot_names.size()); slot_names.push_back(nm); }
+    }
+    refchr_slot.resize(ref.chr_names.size());
+    for (size_t i = 0; i < ref.chr_names.size(); i++) refchr_slot[i] = slot_of[ref.chr_names[i]];
+
+    // planes: owned references only
+    chr_base.assign(n, 0);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        chr_base[i] = off;
+        if (chr_owned[i]) off += (((uint64_t)chr_len[i] + 1 + 63) / 64) * 64;
+    }
+    plane_stride = off;
+    if (plane_stride >= dev::kJuncMaxGlobal) return fail(IRF_E_RANGE, "genome too large for the packed junction key (>= 2^34 bases)");
+    TRY(upload(this, d_chr_base, chr_base));
+    TRY(upload(this, d_chr_len, chr_len));
+    TRY(upload(this, d_chr_owned, chr_owned));
+    {
+        hipError_t e = d_diff.reserve(2 * plane_stride);
+        if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth planes failed");
+    }
+    TRY(alloc_zero(this, d_chr_cnt, (size_t)n * 2));
+    {
+        hipError_t e = d_ws.reserve(dev::scan_workspace_elems(2 * plane_stride));
+        if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the scan workspace failed");
+    }
+
+    // ---- ROI: (slot,end)-sorted, BAM chromosomes only ----
+    n_roi = (uint32_t)ref.roi_start.size();
+    {
+        std::vector<uint32_t> idx;
+        for (uint32_t i = 0; i < n_roi; i++) if (refchr_slot[ref.roi_chr[i]] < n) idx.push_back(i);
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+            uint32_t sa = refchr_slot[ref.roi_chr[a]], sb = refchr_slot[ref.roi_chr[b]];
+            if (sa != sb) return sa < sb;
+            return ref.roi_end[a] < ref.roi_end[b];
+        });
+        std::vector<uint32_t> offv(n + 1, 0), s, e, fi;
+        for (uint32_t i : idx) { offv[refchr_slot[ref.roi_chr[i]] + 1]++; s.push_back(ref.roi_start[i]); e.push_back(ref.roi_end[i]); fi.push_back(i); }
+        for (uint32_t i = 0; i < n; i++) offv[i + 1] += offv[i];
+        TRY(upload(this, d_roi_off, offv));
+        TRY(upload(this, d_roi_start, s));
+        TRY(upload(this, d_roi_end, e));
+        TRY(upload(this, d_roi_idx, fi));
+        TRY(alloc_zero(this, d_roi_cnt, (size_t)n_roi * 2));
+    }
+    // ---- SpansPoint: (slot,pos)-sorted; reference-only chromosomes at the tail ----
+    n_sp = (uint32_t)ref.sp_pos.size();
+    {
+        std::vector<uint64_t> key(n_sp);
+        for (uint32_t i = 0; i < n_sp; i++) key[i] = ((uint64_t)refchr_slot[ref.sp_chr[i]] << 32) | ref.sp_pos[i];
+        std::sort(key.begin(), key.end());
+        sp_slot.resize(n_sp);
+        sp_pos_sorted.resize(n_sp);
+        std::vector<uint32_t> offv(n + 1, 0);
+        for (uint32_t i = 0; i < n_sp; i++) {
+            sp_slot[i] = (uint32_t)(key[i] >> 32);
+            sp_pos_sorted[i] = (uint32_t)key[i];
+            if (sp_slot[i] < n) offv[sp_slot[i] + 1]++;
+        }
+        for (uint32_t i = 0; i < n; i++) offv[i + 1] += offv[i];
+        TRY(upload(this, d_sp_off, offv));
+        TRY(upload(this, d_sp_pos, sp_pos_sorted));
+        TRY(alloc_zero(this, d_sp_cnt, (size_t)n_sp * 2));
+    }
+    // ---- known junctions sorted by (slot,left,right) ----
+    {
+        size_t nk = ref.kj_left.size();
+        std::vector<uint32_t> idx(nk);
+        for (size_t i = 0; i < nk; i++) idx[i] = (uint32_t)i;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+            return refchr_slot[ref.kj_chr[a]] < refchr_slot[ref.kj_chr[b]];
+        });
+        kj_slot.clear(); kj_left.clear(); kj_right.clear(); kj_dir.clear();
+        std::vector<uint64_t> kkeys;
+        std::vector<uint8_t> kdir;
+        for (uint32_t i : idx) {
+            uint32_t sl = refchr_slot[ref.kj_chr[i]];
+            kj_slot.push_back(sl); kj_left.push_back(ref.kj_left[i]); kj_right.push_back(ref.kj_right[i]); kj_dir.push_back(ref.kj_dir[i]);
+            if (sl < n && chr_owned[sl] && ref.kj_right[i] >= ref.kj_left[i]) {
+                uint64_t span = (uint64_t)ref.kj_right[i] - ref.kj_left[i];
+                if (span < (1ull << dev::kJuncSpanBits)) {
+                    kkeys.push_back(((chr_base[sl] + ref.kj_left[i]) << dev::kJuncSpanBits) | span);
+                    kdir.push_back(ref.kj_dir[i]);
+                }
+            }
+        }
+        n_known_dev = (uint32_t)kkeys.size();
+        TRY(upload(this, d_known_keys, kkeys));
+        TRY(upload(this, d_known_dir, kdir));
+    }
+    // ---- introns ----
+    n_intron = (uint32_t)ref.n_intron();
+    {
+        std::vector<uint8_t> valid(n_intron), plus(n_intron);
+        std::vector<uint64_t> gs(n_intron), ge(n_intron), bgs(ref.blk_start.size());
+        std::vector<uint32_t> bl(ref.blk_start.size());
+        std::vector<int32_t> sis(n_intron, -1), sie(n_intron, -1), usi(n_intron, -1), uei(n_intron, -1);
+        std::vector<uint64_t> us, ue;
+        for (uint32_t i = 0; i < n_intron; i++) {
+            uint32_t sl = refchr_slot[ref.in_chr[i]];
+            bool ok = sl < n && chr_owned[sl] && ref.in_end[i] <= chr_len[sl];
+            for (uint32_t b = ref.in_blk_off[i]; ok && b < ref.in_blk_off[i + 1]; b++)
+                if (ref.blk_end[b] > chr_len[sl] || ref.blk_end[b] < ref.blk_start[b]) ok = false;
+            valid[i] = ok;
+            plus[i] = ref.in_strand[i] != '-';
+            uint64_t base = ok ? chr_base[sl] : 0;
+            gs[i] = base + ref.in_start[i];
+            ge[i] = base + ref.in_end[i];
+            for (uint32_t b = ref.in_blk_off[i]; b < ref.in_blk_off[i + 1]; b++) {
+                bgs[b] = base + ref.blk_start[b];
+                bl[b] = ref.blk_end[b] >= ref.blk_start[b] ? ref.blk_end[b] - ref.blk_start[b] : 0;
+            }
+            if (ok) {
+                us.push_back(gs[i]); ue.push_back(ge[i]);
+                // SpansPoint index of Start / End
+                auto find_sp = [&](uint32_t pos) -> int32_t {
+                    uint64_t k = ((uint64_t)sl << 32) | pos;
+                    size_t lo = 0, hi = n_sp;
+                    while (lo < hi) {
+                        size_t mid = (lo + hi) / 2;
+                        uint64_t km = ((uint64_t)sp_slot[mid] << 32) | sp_pos_sorted[mid];
+                        if (km < k) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < n_sp && sp_slot[lo] == sl && sp_pos_sorted[lo] == pos) return (int32_t)lo;
+                    return -1;
+                };
+                sis[i] = find_sp(ref.in_start[i]);
+                sie[i] = find_sp(ref.in_end[i]);
+            }
+        }
+        std::sort(us.begin(), us.end()); us.erase(std::unique(us.begin(), us.end()), us.end());
+        std::sort(ue.begin(), ue.end()); ue.erase(std::unique(ue.begin(), ue.end()), ue.end());
+        for (uint32_t i = 0; i < n_intron; i++) if (valid[i]) {
+            usi[i] = (int32_t)(std::lower_bound(us.begin(), us.end(), gs[i]) - us.begin());
+            uei[i] = (int32_t)(std::lower_bound(ue.begin(), ue.end(), ge[i]) - ue.begin());
+        }
+        n_us = (uint32_t)us.size(); n_ue = (uint32_t)ue.size();
+        TRY(upload(this, d_in_valid, valid)); TRY(upload(this, d_in_plus, plus));
+        TRY(upload(this, d_in_gstart, gs)); TRY(upload(this, d_in_gend, ge));
+        TRY(upload(this, d_in_blk_off, ref.in_blk_off));
+        TRY(upload(this, d_blk_gstart, bgs)); TRY(upload(this, d_blk_len, bl));
+        TRY(upload(this, d_in_measured, ref.in_measured));
+        TRY(upload(this, d_sp_idx_s, sis)); TRY(upload(this, d_sp_idx_e, sie));
+        TRY(upload(this, d_us_idx, usi)); TRY(upload(this, d_ue_idx, uei));
+        TRY(upload(this, d_us_pos, us)); TRY(upload(this, d_ue_pos, ue));
+        TRY(alloc_zero(this, d_left_cnt, (size_t)n_us * 2));
+        TRY(alloc_zero(this, d_right_cnt, (size_t)n_ue * 2));
+        for (int t = 0; t < 2; t++) {
+            TRY(alloc_zero(this, d_out_f64[t], (size_t)n_intron * 8));
+            TRY(alloc_zero(this, d_out_u32[t], (size_t)n_intron * 6));
+        }
+    }
+    TRY(alloc_zero(this, d_scalars, 8));
+    TRY(alloc_zero(this, d_err, 1));
+    {
+        uint64_t cap = std::max<uint64_t>(P.junc_event_capacity, 1024);
+        hipError_t e = d_junc_a.reserve(cap);
+        if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the junction event buffer failed");
+    }
+    have_map = true;
+    return zero_counters();
+}
+
+int irf_ctx::zero_counters() {
+    HIP_TRY(hipSetDevice(device));
+    if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
+    if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
+    if (n_roi) HIP_TRY(hipMemsetAsync(d_roi_cnt.p, 0, (size_t)n_roi * 2 * sizeof(uint32_t), stream));
+    if (n_sp) HIP_TRY(hipMemsetAsync(d_sp_cnt.p, 0, (size_t)n_sp * 2 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(d_scalars.p, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), stream));
+    n_fragments = n_blocks = junc_upper = 0;
+    n_unique = n_events = 0;
+    finalized = results_ready = false;
+    directionality = 0;
+    count_events_used = 0;
+    memset(&timing, 0, sizeof timing);
+    return 0;
+}
+
+dev::CountTables irf_ctx::count_tables() {
+    dev::CountTables T;
+    memset(&T, 0, sizeof T);
+    T.n_chr = n_chr; T.n_roi = n_roi; T.n_sp = n_sp;
+    T.junc_min_flank = P.junc_min_flank;
+    T.sp_min_len = P.sp_overhang_left + P.sp_overhang_right;
+    T.sp_lo_add = P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u);
+    T.sp_hi_sub = P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u);
+    T.plane_stride = plane_stride;
+    T.junc_capacity = d_junc_a.cap;
+    T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
+    T.diff = d_diff.p; T.chr_cnt = d_chr_cnt.p;
+    T.roi_off = d_roi_off.p; T.roi_start = d_roi_start.p; T.roi_end = d_roi_end.p; T.roi_idx = d_roi_idx.p; T.roi_cnt = d_roi_cnt.p;
+    T.sp_off = d_sp_off.p; T.sp_pos = d_sp_pos.p; T.sp_cnt = d_sp_cnt.p;
+    T.junc_keys = d_junc_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
+    return T;
+}
+
+// The event buffer must hold every junction a batch can emit (< n_blk).  Uses a host-side upper bound and
+// only synchronises to read the true count when the bound is exceeded; grows by doubling (HBM is plentiful).
+int irf_ctx::ensure_junc_capacity(uint64_t n_blk) {
+    if (junc_upper + n_blk <= d_junc_a.cap) { junc_upper += n_blk; return 0; }
+    HIP_TRY(hipStreamSynchronize(stream));
+    unsigned long long cur = 0;
+    HIP_TRY(hipMemcpy(&cur, d_scalars.p, sizeof cur, hipMemcpyDeviceToHost));
+    if (cur > d_junc_a.cap) return fail(IRF_E_RANGE, "junction event buffer overflowed");
+    if (cur + n_blk > d_junc_a.cap) {
+        uint64_t ncap = std::max<uint64_t>(d_junc_a.cap * 2, cur + n_blk);
+        uint64_t* np = nullptr;
+        HIP_TRY(hipMalloc((void**)&np, ncap * sizeof(uint64_t)));
+        if (cur) HIP_TRY(hipMemcpy(np, d_junc_a.p, cur * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+        d_junc_a.release();
+        d_junc_a.p = np; d_junc_a.cap = ncap;
+    }
+    junc_upper = cur + n_blk;
+    return 0;
+}
+
+int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
+    if (!have_map) return fail(IRF_E_STATE, "irf_submit_batch before irf_chr_map_update");
+    if (finalized) return fail(IRF_E_STATE, "irf_submit_batch after irf_finalize (call irf_reset first)");
+    if (!b) return fail(IRF_E_ARG, "null batch");
+    if (b->n_frag && (!b->frag_chr || !b->frag_flags || !b->frag_start || !b->frag_end || !b->frag_blk_off))
+        return fail(IRF_E_ARG, "null fragment array");
+    if (b->n_blk && (!b->blk_start || !b->blk_len || !b->blk_read)) return fail(IRF_E_ARG, "null block array");
+    if (b->mem_kind != IRF_MEM_HOST && b->mem_kind != IRF_MEM_DEVICE) return fail(IRF_E_ARG, "bad mem_kind");
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t bid = next_batch_id++;
+    if (id) *id = bid;
+    if (b->n_frag == 0) return 0;
+    if (n_fragments + b->n_frag > 0xffffffffull) return fail(IRF_E_RANGE, "more than 2^32-1 fragments in one context (uint32 counters)");
+    if (b->mem_kind == IRF_MEM_HOST) {
+        // the CSR offsets are the one thing the kernel trusts for addressing: check them on the host
+        if (b->frag_blk_off[0] != 0 || b->frag_blk_off[b->n_frag] != b->n_blk) return fail(IRF_E_ARG, "frag_blk_off does not span [0, n_blk]");
+        for (uint32_t i = 0; i < b->n_frag; i++)
+            if (b->frag_blk_off[i] > b->frag_blk_off[i + 1]) return fail(IRF_E_ARG, "frag_blk_off is not non-decreasing");
+    }
+    TRY(ensure_junc_capacity(b->n_blk));
+    dev::BatchDev B;
+    memset(&B, 0, sizeof B);
+    B.n_frag = b->n_frag; B.n_blk = b->n_blk;
+    Staging* st = nullptr;
+    if (b->mem_kind == IRF_MEM_DEVICE) {
+        B.frag_chr = b->frag_chr; B.frag_flags = b->frag_flags; B.frag_start = b->frag_start; B.frag_end = b->frag_end;
+        B.frag_blk_off = b->frag_blk_off; B.blk_start = b->blk_start; B.blk_len = b->blk_len; B.blk_read = b->blk_read;
+    } else {
+        st = &stage[bid & 1];
+        if (st->in_use) HIP_TRY(hipEventSynchronize(st->consumed));      // the kernel reading this slot has finished
+        size_t nf = b->n_frag, nb = std::max<uint32_t>(b->n_blk, 1);
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = st->frag_chr.reserve(nf);
+        if (e == hipSuccess) e = st->frag_flags.reserve(nf);
+        if (e == hipSuccess) e = st->frag_start.reserve(nf);
+        if (e == hipSuccess) e = st->frag_end.reserve(nf);
+        if (e == hipSuccess) e = st->frag_blk_off.reserve(nf + 1);
+        if (e == hipSuccess) e = st->blk_start.reserve(nb);
+        if (e == hipSuccess) e = st->blk_len.reserve(nb);
+        if (e == hipSuccess) e = st->blk_read.reserve(nb);
+        if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the staging buffers failed");
+        HIP_TRY(hipMemcpyAsync(st->frag_chr.p, b->frag_chr, nf * 4, hipMemcpyHostToDevice, copy_stream));
+        HIP_TRY(hipMemcpyAsync(st->frag_flags.p, b->frag_flags, nf, hipMemcpyHostToDevice, copy_stream));
+        HIP_TRY(hipMemcpyAsync(st->frag_start.p, b->frag_start, nf * 4, hipMemcpyHostToDevice, copy_stream));
+        HIP_TRY(hipMemcpyAsync(st->frag_end.p, b->frag_end, nf * 4, hipMemcpyHostToDevice, copy_stream));
+        HIP_TRY(hipMemcpyAsync(st->frag_blk_off.p, b->frag_blk_off, (nf + 1) * 4, hipMemcpyHostToDevice, copy_stream));
+        if (b->n_blk) {
+            HIP_TRY(hipMemcpyAsync(st->blk_start.p, b->blk_start, (size_t)b->n_blk * 4, hipMemcpyHostToDevice, copy_stream));
+            HIP_TRY(hipMemcpyAsync(st->blk_len.p, b->blk_len, (size_t)b->n_blk * 4, hipMemcpyHostToDevice, copy_stream));
+            HIP_TRY(hipMemcpyAsync(st->blk_read.p, b->blk_read, (size_t)b->n_blk, hipMemcpyHostToDevice, copy_stream));
+        }
+        HIP_TRY(hipEventRecord(st->copied, copy_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, st->copied, 0));
+        st->batch_id = bid; st->in_use = true;
+        B.frag_chr = st->frag_chr.p; B.frag_flags = st->frag_flags.p; B.frag_start = st->frag_start.p; B.frag_end = st->frag_end.p;
+        B.frag_blk_off = st->frag_blk_off.p; B.blk_start = st->blk_start.p; B.blk_len = st->blk_len.p; B.blk_read = st->blk_read.p;
+    }
+    if (count_events_used == count_events.size()) {
+        hipEvent_t a, z;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&z));
+        count_events.emplace_back(a, z);
+    }
+    auto& evp = count_events[count_events_used++];
+    HIP_TRY(hipEventRecord(evp.first, stream));
+    dev::launch_count(count_tables(), B, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(evp.second, stream));
+    if (st) HIP_TRY(hipEventRecord(st->consumed, stream));
+    n_fragments += b->n_frag;
+    n_blocks += b->n_blk;
+    return 0;
+}
+
+int irf_ctx::wait(uint64_t id) {
+    HIP_TRY(hipSetDevice(device));
+    for (auto& s : stage)
+        if (s.in_use && s.batch_id == id) HIP_TRY(hipEventSynchronize(s.copied));
+    return 0;    // older batches were waited for when their slot was reused
+}
+
+int irf_ctx::finalize() {
+    if (!have_map) return fail(IRF_E_STATE, "irf_finalize before irf_chr_map_update");
+    if (finalized) return 0;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(copy_stream));
+    HIP_TRY(hipEventRecord(ev[0], stream));
+    // ---- junction events -> sorted unique table ----
+    unsigned long long scal[8];
+    uint32_t errf = 0;
+    HIP_TRY(hipMemcpyAsync(scal, d_scalars.p, sizeof scal, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&errf, d_err.p, sizeof errf, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (errf) {
+        char m[160];
+        snprintf(m, sizeof m, "count kernel reported input errors (flags 0x%x: 1 chr id, 2 block beyond chromosome, 4 junction range, 8 junction capacity)", errf);
+        return fail(errf & dev::ERR_JUNC_CAPACITY ? IRF_E_STATE : IRF_E_RANGE, m);
+    }
+    n_events = scal[0];
+    if (n_events > 0xffffffffull) return fail(IRF_E_RANGE, "more than 2^32-1 junction events");
+    n_unique = 0;
+    d_sorted = d_junc_a.p;
+    if (n_events) {
+        if (d_junc_b.reserve(d_junc_a.cap) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort buffer failed");
+        uint64_t ws_need = std::max(dev::radix_workspace_elems(n_events), dev::scan_workspace_elems(std::max<uint64_t>(n_events, 2 * plane_stride)));
+        if (ws_need > d_ws.cap) { if (d_ws.reserve(ws_need) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort workspace failed"); }
+        unsigned long long init[2] = {0ull, ~0ull};
+        HIP_TRY(hipMemcpyAsync(d_scalars.p + 1, init, sizeof init, hipMemcpyHostToDevice, stream));
+        dev::launch_key_bits(d_junc_a.p, n_events, d_scalars.p + 1, stream);
+        unsigned long long bits[2];
+        HIP_TRY(hipMemcpyAsync(bits, d_scalars.p + 1, sizeof bits, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const unsigned long long varying = bits[0] ^ bits[1];
+        uint64_t* src = d_junc_a.p;
+        uint64_t* dst = d_junc_b.p;
+        for (int shift = 0; shift < 64; shift += 8) {
+            if (((varying >> shift) & 0xffull) == 0) continue;     // digit identical in every key
+            dev::launch_radix_pass(src, dst, n_events, shift, d_ws.p, stream);
+            std::swap(src, dst);
+        }
+        d_sorted = src;
+        if (d_flags.reserve(n_events) != hipSuccess || d_uidx.reserve(n_events) != hipSuccess)
+            return fail(IRF_E_NOMEM, "hipMalloc of the junction compaction buffers failed");
+        dev::launch_head_flags(src, n_events, d_flags.p, stream);
+        dev::launch_exclusive_scan_u32(d_flags.p, d_uidx.p, n_events, d_ws.p, stream);
+        uint32_t last[2];
+        HIP_TRY(hipMemcpyAsync(&last[0], d_uidx.p + (n_events - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&last[1], d_flags.p + (n_events - 1), 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        n_unique = (uint64_t)last[0] + last[1];
+        if (d_ukeys.reserve(n_unique) != hipSuccess || d_ustart.reserve(n_unique) != hipSuccess || d_ucount.reserve(n_unique) != hipSuccess)
+            return fail(IRF_E_NOMEM, "hipMalloc of the junction table failed");
+        dev::launch_unique_runs(src, d_flags.p, d_uidx.p, n_events, d_ukeys.p, d_ustart.p, stream);
+        dev::launch_run_lengths(d_ustart.p, n_unique, n_events, d_ucount.p, stream);
+    }
+    // ---- SpliceLeft / SpliceRight per intron boundary, directionality vote ----
+    if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));
+    if (n_ue) HIP_TRY(hipMemsetAsync(d_right_cnt.p, 0, (size_t)n_ue * 2 * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_scalars.p + 3, 0, 2 * sizeof(unsigned long long), stream));
+    if (n_unique) {
+        dev::JuncLookupTables J;
+        memset(&J, 0, sizeof J);
+        J.ukeys = d_ukeys.p; J.ucount = d_ucount.p; J.n_unique = n_unique;
+        J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
+        J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
+        J.known_keys = d_known_keys.p; J.known_dir = d_known_dir.p; J.n_known = n_known_dev;
+        J.dir_votes = d_scalars.p + 3;
+        dev::launch_junction_lookups(J, stream);
+    }
+    unsigned long long votes[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(votes, d_scalars.p + 3, sizeof votes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    // ---- depth: prefix scan of the difference planes, in place ----
+    dev::launch_inclusive_scan_i32(d_diff.p, 2 * plane_stride, d_ws.p, stream);
+    HIP_TRY(hipEventRecord(ev[2], stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    // JunctionCount::Directional() (OQ-5)
+    directionality = 0;
+    if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
+    else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
+    // ---- per-intron statistics and IR rows ----
+    for (int t = 0; t < 2; t++) {
+        if (t == 1 && directionality == 0) break;
+        dev::IntronTables T;
+        memset(&T, 0, sizeof T);
+        T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.depth = d_diff.p;
+        T.valid = d_in_valid.p; T.strand_plus = d_in_plus.p; T.g_start = d_in_gstart.p; T.g_end = d_in_gend.p;
+        T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
+        T.sp_idx_start = d_sp_idx_s.p; T.sp_idx_end = d_sp_idx_e.p; T.sp_cnt = d_sp_cnt.p;
+        T.us_idx = d_us_idx.p; T.ue_idx = d_ue_idx.p; T.left_cnt = d_left_cnt.p; T.right_cnt = d_right_cnt.p;
+        T.n_ustart = n_us; T.n_uend = n_ue;
+        T.ukeys = d_ukeys.p; T.ucount = d_ucount.p; T.n_unique = n_unique;
+        T.trim_centre_pct = P.trim_centre_pct; T.pct_interpolate = P.pct_interpolate;
+        T.flank_offset = P.flank_offset; T.flank_len = P.flank_len; T.flank_use_measured = P.flank_use_measured;
+        T.directionality = t == 0 ? 0 : directionality;
+        T.warn_lowcover_min = P.warn_lowcover_min; T.warn_lowsplice_min = P.warn_lowsplice_min;
+        T.warn_minor_ratio = P.warn_minor_ratio; T.warn_nonuniform_rel = P.warn_nonuniform_rel;
+        T.warn_nonuniform_abs = P.warn_nonuniform_abs;
+        T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
+        dev::launch_intron_stats(T, stream);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[3], stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    // ---- timing ----
+    float ms = 0;
+    timing.count_ms = 0;
+    for (size_t i = 0; i < count_events_used; i++) {
+        if (hipEventElapsedTime(&ms, count_events[i].first, count_events[i].second) == hipSuccess) timing.count_ms += ms;
+    }
+    timing.n_count_launches = (uint32_t)count_events_used;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) timing.junction_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) timing.scan_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.stats_ms = ms;
+    timing.table_ms = 0;       // the IR rows are written by the statistics kernel itself
+    if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) timing.total_finalize_ms = ms;
+    finalized = true;
+    results_ready = false;
+    return 0;
+}
+
+// Device -> host, plus the host-side joins that only the text writers need
+// (known ∪ observed junctions with strand annotation).
+int irf_ctx::fetch_results() {
+    if (!finalized) return fail(IRF_E_STATE, "results requested before irf_finalize");
+    if (results_ready) return 0;
+    HIP_TRY(hipSetDevice(device));
+    std::vector<uint32_t> tmp;
+    auto down32 = [&](const uint32_t* p, size_t n) -> hipError_t {
+        tmp.resize(n);
+        if (!n) return hipSuccess;
+        return hipMemcpy(tmp.data(), p, n * 4, hipMemcpyDeviceToHost);
+    };
+    HIP_TRY(down32(d_chr_cnt.p, (size_t)n_chr * 2));
+    h_chr_cnt.assign(tmp.begin(), tmp.end());
+    HIP_TRY(down32(d_roi_cnt.p, (size_t)n_roi * 2));
+    h_roi_cnt.assign(tmp.begin(), tmp.end());
+    HIP_TRY(down32(d_sp_cnt.p, (size_t)n_sp * 2));
+    h_sp_cnt = tmp;
+    h_sp_chr = sp_slot;
+    h_sp_pos = sp_pos_sorted;
+    // junctions: decode the unique keys, pair the two strands, merge with the known table
+    {
+        std::vector<uint64_t> uk(n_unique);
+        std::vector<uint32_t> uc(n_unique);
+        if (n_unique) {
+            HIP_TRY(hipMemcpy(uk.data(), d_ukeys.p, n_unique * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(uc.data(), d_ucount.p, n_unique * 4, hipMemcpyDeviceToHost));
+        }
+        std::vector<uint32_t> oc, ol, orr, c0, c1;
+        uint32_t chr = 0;
+        for (uint64_t u = 0; u < n_unique; u++) {
+            uint64_t gl = uk[u] >> dev::kJuncLeftShift;
+            uint32_t span = (uint32_t)((uk[u] >> 1) & ((1ull << dev::kJuncSpanBits) - 1));
+            uint32_t d = (uint32_t)(uk[u] & 1);
+            while (chr + 1 < n_chr && (!chr_owned[chr] || gl >= chr_base[chr] + ((((uint64_t)chr_len[chr] + 1 + 63) / 64) * 64))) chr++;
+            uint32_t left = (uint32_t)(gl - chr_base[chr]);
+            if (!oc.empty() && oc.back() == chr && ol.back() == left && orr.back() == left + span) {
+                (d ? c1 : c0).back() += uc[u];
+            } else {
+                oc.push_back(chr); ol.push_back(left); orr.push_back(left + span);
+                c0.push_back(d ? 0 : uc[u]); c1.push_back(d ? uc[u] : 0);
+            }
+        }
+        h_j_chr.clear(); h_j_left.clear(); h_j_right.clear(); h_j_refdir.clear();
+        std::vector<uint32_t> m0, m1;
+        size_t a = 0, b = 0, na = oc.size(), nb = kj_left.size();
+        auto less_ab = [&](size_t i, size_t j) {      // observed[i] < known[j]
+            if (oc[i] != kj_slot[j]) return oc[i] < kj_slot[j];
+            if (ol[i] != kj_left[j]) return ol[i] < kj_left[j];
+            return orr[i] < kj_right[j];
+        };
+        auto eq_ab = [&](size_t i, size_t j) { return oc[i] == kj_slot[j] && ol[i] == kj_left[j] && orr[i] == kj_right[j]; };
+        while (a < na || b < nb) {
+            if (a < na && b < nb && eq_ab(a, b)) {
+                h_j_chr.push_back(oc[a]); h_j_left.push_back(ol[a]); h_j_right.push_back(orr[a]);
+                m0.push_back(c0[a]); m1.push_back(c1[a]); h_j_refdir.push_back(kj_dir[b]);
+                a++; b++;
+            } else if (b >= nb || (a < na && less_ab(a, b))) {
+                h_j_chr.push_back(oc[a]); h_j_left.push_back(ol[a]); h_j_right.push_back(orr[a]);
+                m0.push_back(c0[a]); m1.push_back(c1[a]); h_j_refdir.push_back(0);
+                a++;
+            } else {
+                h_j_chr.push_back(kj_slot[b]); h_j_left.push_back(kj_left[b]); h_j_right.push_back(kj_right[b]);
+                m0.push_back(0); m1.push_back(0); h_j_refdir.push_back(kj_dir[b]);
+                b++;
+            }
+        }
+        h_j_cnt = m0;
+        h_j_cnt.insert(h_j_cnt.end(), m1.begin(), m1.end());
+    }
+    for (int t = 0; t < 2; t++) {
+        if (t == 1 && directionality == 0) { h_f64[1].clear(); h_u32[1].clear(); h_warn[1].clear(); break; }
+        h_f64[t].resize((size_t)n_intron * 8);
+        h_u32[t].resize((size_t)n_intron * 6);
+        if (n_intron) {
+            HIP_TRY(hipMemcpy(h_f64[t].data(), d_out_f64[t].p, h_f64[t].size() * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(h_u32[t].data(), d_out_u32[t].p, h_u32[t].size() * 4, hipMemcpyDeviceToHost));
+        }
+        h_warn[t].resize(n_intron);
+        for (uint32_t i = 0; i < n_intron; i++) h_warn[t][i] = (uint8_t)h_u32[t][(size_t)5 * n_intron + i];
+    }
+    results_ready = true;
+    return 0;
+}
+
+// ============================================================================
+extern "C" {
+
+void irf_params_default(irf_params* p) {
+    memset(p, 0, sizeof *p);
+    p->struct_size = (uint32_t)sizeof *p;
+    p->skip_flag_mask = 0x4;
+    p->pair_long_inclusive = 0;
+    p->pair_short_inclusive = 1;
+    p->junc_min_flank = 5;
+    p->sp_overhang_left = 5;
+    p->sp_overhang_right = 4;
+    p->sp_inclusive = 0;
+    p->trim_centre_pct = 40;
+    p->pct_interpolate = 1;
+    p->flank_offset = 5;
+    p->flank_len = 50;
+    p->flank_use_measured = 1;
+    p->dir_ratio = 10;
+    p->out_precision = 6;
+    p->warn_lowcover_min = 10.0;
+    p->warn_lowsplice_min = 4.0;
+    p->warn_minor_ratio = 1.33;
+    p->warn_nonuniform_rel = 1.5;
+    p->warn_nonuniform_abs = 4.0;
+    p->junc_event_capacity = 1ull << 26;
+    p->keep_depth = 0;
+}
+
+static void set_err(char* buf, size_t n, const std::string& s) {
+    if (buf && n) { snprintf(buf, n, "%s", s.c_str()); }
+}
+
+int irf_ref_load_mem(const char* const bufs[4], const size_t lens[4], irf_ref** out, char* errbuf, size_t errbuf_len) {
+    if (!bufs || !lens || !out) return IRF_E_ARG;
+    irf_ref* r = new irf_ref();
+    std::string err;
+    bool ok = irf::parse_cover_bed(bufs[0], lens[0], r->t, err) && irf::parse_sj_ref(bufs[1], lens[1], r->t, err) &&
+              irf::parse_read_continues_ref(bufs[2], lens[2], r->t, err) && irf::parse_roi_bed(bufs[3], lens[3], r->t, err);
+    if (!ok) { set_err(errbuf, errbuf_len, err); delete r; return IRF_E_PARSE; }
+    irf::finish_tables(r->t);
+    *out = r;
+    return 0;
+}
+
+int irf_ref_load_files(const char* cover, const char* sj, const char* rc, const char* roi, irf_ref** out, char* errbuf,
+                       size_t errbuf_len) {
+    if (!cover || !sj || !rc || !roi || !out) return IRF_E_ARG;
+    std::string s[4], err;
+    const char* paths[4] = {cover, sj, rc, roi};
+    for (int i = 0; i < 4; i++)
+        if (!irf::read_file(paths[i], s[i], err)) { set_err(errbuf, errbuf_len, err); return IRF_E_IO; }
+    const char* bufs[4] = {s[0].data(), s[1].data(), s[2].data(), s[3].data()};
+    size_t lens[4] = {s[0].size(), s[1].size(), s[2].size(), s[3].size()};
+    return irf_ref_load_mem(bufs, lens, out, errbuf, errbuf_len);
+}
+
+void irf_ref_free(irf_ref* r) { delete r; }
+uint32_t irf_ref_n_intron(const irf_ref* r) { return r ? (uint32_t)r->t.n_intron() : 0; }
+uint32_t irf_ref_n_junction(const irf_ref* r) { return r ? (uint32_t)r->t.kj_left.size() : 0; }
+uint32_t irf_ref_n_point(const irf_ref* r) { return r ? (uint32_t)r->t.sp_pos.size() : 0; }
+uint32_t irf_ref_n_roi(const irf_ref* r) { return r ? (uint32_t)r->t.roi_start.size() : 0; }
+
+int irf_create(const irf_params* params, const irf_ref* ref, int device, irf_ctx** out) {
+    if (!ref || !out) return IRF_E_ARG;
+    irf_params P;
+    if (params) {
+        if (params->struct_size != sizeof(irf_params)) return IRF_E_ARG;
+        P = *params;
+    } else {
+        irf_params_default(&P);
+    }
+    if (P.flank_len > 1024 || P.trim_centre_pct > 100) return IRF_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return IRF_E_DEVICE;
+    irf_ctx* c = new irf_ctx();
+    c->P = P;
+    c->ref = ref->t;
+    c->device = device;
+    int rc = c->init();
+    if (rc != 0) { c->free_events(); delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+void irf_destroy(irf_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->free_events();
+    delete c;
+}
+
+const char* irf_last_error(const irf_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int irf_chr_map_update(irf_ctx* c, uint32_t n_chr, const char* const* names, const uint32_t* lens, const uint8_t* owned) {
+    if (!c) return IRF_E_ARG;
+    if (!names || !lens) return c->fail(IRF_E_ARG, "irf_chr_map_update needs names and lengths");
+    for (uint32_t i = 0; i < n_chr; i++) {
+        if (!names[i]) return c->fail(IRF_E_ARG, "null chromosome name");
+        if (lens[i] > 0x7fffffffu) return c->fail(IRF_E_RANGE, "reference length beyond 2^31-1");
+    }
+    return c->build_map(n_chr, names, lens, owned);
+}
+
+int irf_submit_batch(irf_ctx* c, const irf_batch* b, uint64_t* id) { return c ? c->submit(b, id) : IRF_E_ARG; }
+int irf_wait(irf_ctx* c, uint64_t id) { return c ? c->wait(id) : IRF_E_ARG; }
+int irf_finalize(irf_ctx* c) { return c ? c->finalize() : IRF_E_ARG; }
+
+int irf_reset(irf_ctx* c) {
+    if (!c) return IRF_E_ARG;
+    if (!c->have_map) return c->fail(IRF_E_STATE, "irf_reset before irf_chr_map_update");
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
+    if (hipStreamSynchronize(c->copy_stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipStreamSynchronize");
+    return c->zero_counters();
+}
+
+int irf_get_results(irf_ctx* c, irf_results* out) {
+    if (!c || !out) return IRF_E_ARG;
+    int rc = c->fetch_results();
+    if (rc != 0) return rc;
+    memset(out, 0, sizeof *out);
+    out->directionality = c->directionality;
+    out->n_chr = c->n_chr; out->chr_cnt = c->h_chr_cnt.data();
+    out->n_roi = c->n_roi; out->roi_cnt = c->h_roi_cnt.data();
+    out->n_sp = c->n_sp; out->sp_chr = c->h_sp_chr.data(); out->sp_pos = c->h_sp_pos.data(); out->sp_cnt = c->h_sp_cnt.data();
+    out->n_junc = c->h_j_left.size();
+    out->junc_chr = c->h_j_chr.data(); out->junc_left = c->h_j_left.data(); out->junc_right = c->h_j_right.data();
+    out->junc_cnt = c->h_j_cnt.data(); out->junc_refdir = c->h_j_refdir.data();
+    out->n_intron = c->n_intron;
+    out->has_dir = c->directionality != 0;
+    const size_t n = c->n_intron;
+    for (int t = 0; t < 2; t++) {
+        irf_ir_table& T = t == 0 ? out->nondir : out->dir;
+        if (t == 1 && !out->has_dir) break;
+        const double* f = c->h_f64[t].data();
+        const uint32_t* u = c->h_u32[t].data();
+        T.coverage = f; T.intron_depth = f + n; T.p25 = f + 2 * n; T.p50 = f + 3 * n; T.p75 = f + 4 * n;
+        T.first50 = f + 5 * n; T.last50 = f + 6 * n; T.irratio = f + 7 * n;
+        T.sp_left = u; T.sp_right = u + n; T.splice_left = u + 2 * n; T.splice_right = u + 3 * n; T.splice_exact = u + 4 * n;
+        T.warning = c->h_warn[t].data();
+    }
+    out->n_fragments = c->n_fragments; out->n_blocks = c->n_blocks; out->n_junction_events = c->n_events;
+    return 0;
+}
+
+const char* irf_chr_name(const irf_ctx* c, uint32_t slot) {
+    return (c && slot < c->slot_names.size()) ? c->slot_names[slot].c_str() : nullptr;
+}
+uint32_t irf_n_chr_slots(const irf_ctx* c) { return c ? (uint32_t)c->slot_names.size() : 0; }
+
+int irf_get_depth(irf_ctx* c, uint32_t chr, uint32_t start, uint32_t end, uint32_t dir, uint32_t* out) {
+    if (!c || !out) return IRF_E_ARG;
+    if (!c->finalized) return c->fail(IRF_E_STATE, "irf_get_depth before irf_finalize");
+    if (chr >= c->n_chr || !c->chr_owned[chr] || start > end || end > c->chr_len[chr] || dir > 2) return c->fail(IRF_E_ARG, "irf_get_depth: bad range");
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
+    size_t n = end - start;
+    if (!n) return 0;
+    std::vector<uint32_t> a(n), b;
+    int p0 = dir == 2 ? 0 : (int)dir;
+    if (hipMemcpy(a.data(), c->d_diff.p + (uint64_t)p0 * c->plane_stride + c->chr_base[chr] + start, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return c->fail(IRF_E_DEVICE, "hipMemcpy depth");
+    if (dir == 2) {
+        b.resize(n);
+        if (hipMemcpy(b.data(), c->d_diff.p + c->plane_stride + c->chr_base[chr] + start, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return c->fail(IRF_E_DEVICE, "hipMemcpy depth");
+        for (size_t i = 0; i < n; i++) a[i] += b[i];
+    }
+    memcpy(out, a.data(), n * 4);
+    return 0;
+}
+
+int irf_export_device(irf_ctx* c, uint32_t what, void* dst, uint64_t* n_out) {
+    if (!c || !n_out) return IRF_E_ARG;
+    if (!c->finalized) return c->fail(IRF_E_STATE, "irf_export_device before irf_finalize");
+    const void* src = nullptr;
+    uint64_t n = 0;
+    size_t elem = 4;
+    switch (what) {
+        case IRF_COL_IR_NONDIR_F64: src = c->d_out_f64[0].p; n = (uint64_t)c->n_intron * 8; elem = 8; break;
+        case IRF_COL_IR_NONDIR_U32: src = c->d_out_u32[0].p; n = (uint64_t)c->n_intron * 6; break;
+        case IRF_COL_IR_DIR_F64: src = c->d_out_f64[1].p; n = c->directionality ? (uint64_t)c->n_intron * 8 : 0; elem = 8; break;
+        case IRF_COL_IR_DIR_U32: src = c->d_out_u32[1].p; n = c->directionality ? (uint64_t)c->n_intron * 6 : 0; break;
+        case IRF_COL_JUNC_KEYS: src = c->d_ukeys.p; n = c->n_unique; elem = 8; break;
+        case IRF_COL_JUNC_COUNTS: src = c->d_ucount.p; n = c->n_unique; break;
+        case IRF_COL_SP_CNT: src = c->d_sp_cnt.p; n = (uint64_t)c->n_sp * 2; break;
+        case IRF_COL_ROI_CNT: src = c->d_roi_cnt.p; n = (uint64_t)c->n_roi * 2; break;
+        case IRF_COL_CHR_CNT: src = c->d_chr_cnt.p; n = (uint64_t)c->n_chr * 2; break;
+        default: return c->fail(IRF_E_ARG, "irf_export_device: unknown column");
+    }
+    *n_out = n;
+    if (!dst || !n) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
+    if (hipMemcpyAsync(dst, src, n * elem, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipMemcpy D2D");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipStreamSynchronize");
+    return 0;
+}
+
+int irf_get_timing(irf_ctx* c, irf_timing* out) {
+    if (!c || !out) return IRF_E_ARG;
+    *out = c->timing;
+    return 0;
+}
+
+}   // extern "C"
+
+// accessors for the writers (writers.cpp), which live in the same library
+namespace irf {
+const RefTables& ctx_ref(const irf_ctx* c) { return c->ref; }
+const irf_params& ctx_params(const irf_ctx* c) { return c->P; }
+const std::vector<uint32_t>& ctx_refchr_slot(const irf_ctx* c) { return c->refchr_slot; }
+const std::vector<std::string>& ctx_slot_names(const irf_ctx* c) { return c->slot_names; }
+int ctx_fail(irf_ctx* c, int code, const std::string& msg) { return c->fail(code, msg); }
+}   // namespace irf

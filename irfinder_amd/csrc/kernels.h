@@ -1,0 +1,148 @@
+// kernels.h — launch interface between the engine (engine.hip) and the gfx950
+// kernels (count.hip, scan.hip, radix.hip, stats.hip).  Plain structs of device
+// pointers; every launcher is asynchronous on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace irf {
+namespace dev {
+
+// ---- layout of the packed junction key -----------------------------------
+// key = (global_left << 29) | (span << 1) | dir      (63 bits used)
+//   global_left = chr_base[refID] + left   (< 2^34)
+//   span        = right - left             (< 2^28, the BAM cigar length limit)
+constexpr int kJuncSpanBits = 28;
+constexpr int kJuncLeftShift = kJuncSpanBits + 1;
+constexpr uint64_t kJuncMaxGlobal = 1ull << 34;
+
+enum ErrBits : uint32_t {
+    ERR_CHR_RANGE = 1u,        // frag_chr >= n_chr
+    ERR_BLOCK_RANGE = 2u,      // block end beyond the chromosome length
+    ERR_JUNC_RANGE = 4u,       // junction span or coordinate does not fit the packed key
+    ERR_JUNC_CAPACITY = 8u,    // junction event buffer full (host sizing bug)
+    ERR_STATS_DEPTH = 16u      // depth beyond what the rank-select levels cover
+};
+
+struct CountTables {
+    uint32_t n_chr;
+    uint32_t n_roi;
+    uint32_t n_sp;
+    uint32_t junc_min_flank;
+    uint32_t sp_min_len;       // block is considered only if len > sp_min_len (= L + R)
+    uint32_t sp_lo_add;        // candidates are the points in [bs + sp_lo_add, be - sp_hi_sub]
+    uint32_t sp_hi_sub;
+    uint32_t pad0;
+    uint64_t plane_stride;     // elements per strand plane of the difference array
+    uint64_t junc_capacity;
+    const uint64_t* chr_base;  // [n_chr]  offset of the chromosome inside a plane
+    const uint32_t* chr_len;   // [n_chr]
+    const uint8_t* chr_owned;  // [n_chr]
+    int32_t* diff;             // [2][plane_stride]  +1 at block start, -1 at block end
+    uint32_t* chr_cnt;         // [n_chr][2]
+    const uint32_t* roi_off;   // [n_chr+1] into the (chr,end)-sorted ROI arrays
+    const uint32_t* roi_start;
+    const uint32_t* roi_end;
+    const uint32_t* roi_idx;   // file index of the sorted ROI
+    uint32_t* roi_cnt;         // [2][n_roi]
+    const uint32_t* sp_off;    // [n_chr+1] into the (chr,pos)-sorted points
+    const uint32_t* sp_pos;
+    uint32_t* sp_cnt;          // [2][n_sp]
+    uint64_t* junc_keys;       // event buffer
+    unsigned long long* junc_count;
+    uint32_t* err_flags;
+};
+
+struct BatchDev {
+    uint32_t n_frag, n_blk;
+    const uint32_t* frag_chr;
+    const uint8_t* frag_flags;
+    const uint32_t* frag_start;
+    const uint32_t* frag_end;
+    const uint32_t* frag_blk_off;
+    const uint32_t* blk_start;
+    const uint32_t* blk_len;
+    const uint8_t* blk_read;
+};
+
+void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s);
+
+// ---- scans ----------------------------------------------------------------
+constexpr uint32_t kScanTile = 4096;
+// number of uint32 workspace elements a scan over n elements needs
+uint64_t scan_workspace_elems(uint64_t n);
+// in-place inclusive prefix sum of int32 (wrap-around arithmetic)
+void launch_inclusive_scan_i32(int32_t* data, uint64_t n, uint32_t* workspace, hipStream_t s);
+// exclusive prefix sum, out may alias in
+void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* workspace, hipStream_t s);
+
+// ---- junction radix sort-reduce ---------------------------------------------
+constexpr uint32_t kRadixTile = 4096;
+uint64_t radix_workspace_elems(uint64_t n);     // uint32 elements
+// OR / AND over all keys (to skip constant digits); out[0] = OR, out[1] = AND (pre-set to 0 / ~0)
+void launch_key_bits(const uint64_t* keys, uint64_t n, unsigned long long* out, hipStream_t s);
+// one stable counting pass on digit [shift, shift+8)
+void launch_radix_pass(const uint64_t* in, uint64_t* out, uint64_t n, int shift, uint32_t* workspace, hipStream_t s);
+// sorted keys -> head flags (1 where key differs from predecessor)
+void launch_head_flags(const uint64_t* keys, uint64_t n, uint32_t* flags, hipStream_t s);
+// compaction: unique keys + run lengths.  uidx = exclusive scan of flags.
+void launch_unique_runs(const uint64_t* keys, const uint32_t* flags, const uint32_t* uidx, uint64_t n,
+                        uint64_t* ukeys, uint32_t* ustart, hipStream_t s);
+void launch_run_lengths(const uint32_t* ustart, uint64_t n_unique, uint64_t n, uint32_t* ucount, hipStream_t s);
+
+// ---- junction-derived lookups ------------------------------------------------
+struct JuncLookupTables {
+    const uint64_t* ukeys;       // sorted unique (with dir bit)
+    const uint32_t* ucount;
+    uint64_t n_unique;
+    const uint64_t* ustart_pos;  // sorted unique global intron starts
+    const uint64_t* uend_pos;    // sorted unique global intron ends
+    uint32_t n_ustart, n_uend;
+    uint32_t* left_cnt;          // [2][n_ustart]   SpliceLeft by strand
+    uint32_t* right_cnt;         // [2][n_uend]
+    const uint64_t* known_keys;  // sorted (global_left << 28 | span) of ref-sj junctions on BAM chromosomes
+    const uint8_t* known_dir;
+    uint32_t n_known;
+    unsigned long long* dir_votes;   // [2]: same, opposite
+};
+void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s);
+
+// ---- per-intron statistics + IR table --------------------------------------------
+struct IntronTables {
+    uint32_t n_intron;
+    uint32_t n_sp;
+    uint64_t plane_stride;
+    const int32_t* depth;          // [2][plane_stride] (scanned)
+    const uint8_t* valid;          // [n_intron] chromosome present in the BAM header and owned
+    const uint8_t* strand_plus;    // [n_intron] 1 unless strand == '-'
+    const uint64_t* g_start;       // global start / end of the intron
+    const uint64_t* g_end;
+    const uint32_t* blk_off;       // [n_intron+1]
+    const uint64_t* blk_gstart;    // measured blocks, global coordinates
+    const uint32_t* blk_len;
+    const uint64_t* measured;      // [n_intron]
+    const int32_t* sp_idx_start;   // index into sp_cnt of the point at Start (-1: none)
+    const int32_t* sp_idx_end;
+    const uint32_t* sp_cnt;        // [2][n_sp]
+    const int32_t* us_idx;         // index into left_cnt
+    const int32_t* ue_idx;
+    const uint32_t* left_cnt;
+    const uint32_t* right_cnt;
+    uint32_t n_ustart, n_uend;
+    const uint64_t* ukeys;
+    const uint32_t* ucount;
+    uint64_t n_unique;
+    // parameters
+    uint32_t trim_centre_pct, pct_interpolate, flank_offset, flank_len, flank_use_measured;
+    int32_t directionality;        // 0: non-directional table (both planes)
+    double warn_lowcover_min, warn_lowsplice_min, warn_minor_ratio, warn_nonuniform_rel, warn_nonuniform_abs;
+    // outputs
+    double* out_f64;               // [8][n_intron]
+    uint32_t* out_u32;             // [6][n_intron]  (5 counts + warning)
+    uint32_t* err_flags;
+};
+void launch_intron_stats(const IntronTables& T, hipStream_t s);
+
+}   // namespace dev
+}   // namespace irf

@@ -1,0 +1,399 @@
+// stats.hip — per-intron depth statistics and IR-table rows (gfx950).
+//
+// Replaces CoverageBlocks::fillHist / coverageFromHist / percentileFromHist /
+// trimmedMeanFromHist and the per-row part of
+// CoverageBlocksIRFinder::WriteOutput (⟨upstream⟩
+// ReadBlockProcessor_CoverageBlocks.cpp).  Upstream builds a
+// std::map<depth,count> per intron and walks it; every statistic is a function
+// of the multiset of depths over the intron's measured bases, so here one
+// workgroup per intron answers a handful of rank queries ("value at rank r" and
+// "sum of the r smallest values") exactly, with an 11-bit-per-level radix
+// select over an LDS histogram:
+//   depth < 2048 (the common case): ONE pass over the depth values;
+//   deeper introns: one filtered pass per level and query (rare).
+// The integers that come out are identical to what the map walk yields; the
+// few fp64 operations (divisions, one interpolation) are done in the same order
+// as the CPU restatement, with contraction off, so doubles match bit for bit.
+// HBM-bound: 4 B (one strand) or 8 B (both) per measured base.
+#include "kernels.h"
+
+namespace irf {
+namespace dev {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kBinBits = 11;
+constexpr int kBins = 1 << kBinBits;
+constexpr int kBinsPerThread = kBins / kThreads;   // 8
+constexpr int kMaxFlank = 1024;
+constexpr int kQueries = 8;
+
+struct Query { unsigned long long rank; uint32_t value; unsigned long long sum_below; };
+
+struct Ctx {
+    const int32_t* d0;
+    const int32_t* d1;
+    int plane;          // 0,1: one strand; 2: both
+    bool valid;
+    __device__ __forceinline__ uint32_t val(uint64_t g) const {
+        if (!valid) return 0u;
+        if (plane == 2) return (uint32_t)d0[g] + (uint32_t)d1[g];
+        return (uint32_t)(plane ? d1[g] : d0[g]);
+    }
+};
+
+// Exclusive prefix over the 256 threads of (count, sum); s_w* are LDS scratch of kWaves entries.
+__device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long tsum, uint32_t& pre,
+                                                unsigned long long& pre_sum, uint32_t* s_wc, unsigned long long* s_ws) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t c = tot;
+    unsigned long long s = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t oc = __shfl_up(c, d);
+        unsigned long long os = __shfl_up(s, d);
+        if ((int)lane >= d) { c += oc; s += os; }
+    }
+    if (lane == 63) { s_wc[wave] = c; s_ws[wave] = s; }
+    __syncthreads();
+    uint32_t bc = 0;
+    unsigned long long bs = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++)
+        if (w < (int)wave) { bc += s_wc[w]; bs += s_ws[w]; }
+    pre = bc + c - tot;
+    pre_sum = bs + s - tsum;
+    __syncthreads();
+}
+
+// rank-by-counting sort of n (<= kMaxFlank) LDS values, then the p-th percentile (OQ-7 formula)
+__device__ double window_percentile(const uint32_t* s_win, uint32_t* s_sorted, uint32_t n, uint32_t pct, bool interpolate,
+                                    double* s_out) {
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
+        const uint32_t v = s_win[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t w = s_win[j];
+            r += (w < v || (w == v && j < i)) ? 1u : 0u;
+        }
+        s_sorted[r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double res = 0.0;
+        if (n > 0) {
+            const unsigned long long num = (unsigned long long)(n + 1u) * pct;
+            const unsigned long long k = num / 100ull;
+            const uint32_t rem = (uint32_t)(num % 100ull);
+            if (k < 1) res = (double)s_sorted[0];
+            else if (k >= n) res = (double)s_sorted[n - 1];
+            else {
+                const double vk = (double)s_sorted[k - 1];
+                if (!interpolate || rem == 0) res = vk;
+                else res = vk + ((double)rem / 100.0) * ((double)s_sorted[k] - vk);
+            }
+        }
+        *s_out = res;
+    }
+    __syncthreads();
+    return *s_out;
+}
+
+__global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) {
+    __shared__ uint32_t s_cnt[kBins];
+    __shared__ unsigned long long s_sum[kBins];            // multi-level sums; doubles as the flank-window buffers
+    __shared__ uint32_t s_wc[kWaves];
+    __shared__ unsigned long long s_ws[kWaves];
+    __shared__ uint32_t s_max, s_overflow, s_sel_bin, s_sel_cnt;
+    __shared__ unsigned long long s_total, s_nz, s_sel_sum;
+    __shared__ uint32_t s_qval[kQueries];
+    __shared__ unsigned long long s_qsum[kQueries];
+    __shared__ double s_dbl;
+    __shared__ unsigned long long s_qrank[kQueries];
+    __shared__ uint32_t s_qneed[kQueries];
+    __shared__ uint32_t s_prem[3];
+
+    const uint32_t i = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    Ctx C;
+    C.d0 = T.depth;
+    C.d1 = T.depth + T.plane_stride;
+    C.valid = T.valid[i] != 0;
+    C.plane = 2;
+    if (T.directionality != 0) C.plane = ((T.strand_plus[i] != 0) == (T.directionality > 0)) ? 1 : 0;
+
+    const uint32_t b0 = T.blk_off[i], b1 = T.blk_off[i + 1];
+    const unsigned long long N = T.measured[i];
+    const uint64_t gS = T.g_start[i], gE = T.g_end[i];
+
+    // ---------------- flank windows (first / last flank_len nt, median) ----------------
+    double flank[2] = {0.0, 0.0};
+    {
+        uint32_t* s_win = reinterpret_cast<uint32_t*>(s_sum);
+        uint32_t* s_sorted = s_win + kMaxFlank;
+        const uint64_t ilen = gE - gS;
+        const uint64_t fo = T.flank_offset, fl = T.flank_len;
+        uint64_t w0[2], w1[2];
+        w0[0] = gS + (fo < ilen ? fo : ilen);
+        w1[0] = gS + (fo + fl < ilen ? fo + fl : ilen);
+        w1[1] = gE - (fo < ilen ? fo : ilen);
+        w0[1] = gE - (fo + fl < ilen ? fo + fl : ilen);
+        for (int wi = 0; wi < 2; wi++) {
+            uint32_t n = 0;
+            if (w0[wi] < w1[wi]) {
+                if (T.flank_use_measured) {
+                    for (uint32_t b = b0; b < b1; b++) {
+                        const uint64_t bs = T.blk_gstart[b], be = bs + T.blk_len[b];
+                        const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
+                        if (s < e) {
+                            for (uint64_t x = s + tid; x < e; x += kThreads) s_win[n + (uint32_t)(x - s)] = C.val(x);
+                            n += (uint32_t)(e - s);
+                        }
+                    }
+                } else {
+                    const uint64_t s = w0[wi], e = w1[wi];
+                    for (uint64_t x = s + tid; x < e; x += kThreads) s_win[(uint32_t)(x - s)] = C.val(x);
+                    n = (uint32_t)(e - s);
+                }
+            }
+            __syncthreads();
+            flank[wi] = window_percentile(s_win, s_sorted, n, 50u, T.pct_interpolate != 0, &s_dbl);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- pass A: histogram (clipped), max, total, non-zero ----------------
+    for (int k = tid; k < kBins; k += kThreads) s_cnt[k] = 0;
+    if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; }
+    __syncthreads();
+    {
+        uint32_t vmax = 0;
+        unsigned long long tsum = 0, nz = 0;
+        bool ovf = false;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint64_t bs = T.blk_gstart[b];
+            const uint32_t bl = T.blk_len[b];
+            for (uint32_t x = tid; x < bl; x += kThreads) {
+                const uint32_t v = C.val(bs + x);
+                if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
+                vmax = v > vmax ? v : vmax;
+                tsum += v;
+                nz += v ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            uint32_t om = __shfl_xor(vmax, d);
+            vmax = om > vmax ? om : vmax;
+            tsum += __shfl_xor(tsum, d);
+            nz += __shfl_xor(nz, d);
+        }
+        if ((tid & 63u) == 0) {
+            atomicMax(&s_max, vmax);
+            atomicAdd(&s_total, tsum);
+            atomicAdd(&s_nz, nz);
+        }
+        if (ovf) s_overflow = 1;
+    }
+    __syncthreads();
+    const uint32_t vmax = s_max;
+    const unsigned long long total = s_total, nzc = s_nz;
+
+    // ---------------- the rank queries ----------------
+    // q0,q1: sums below ranks lo / hi of the trimmed mean; q2..q7: values for p25, p50, p75 (ranks k-1 and k)
+    const unsigned long long skip = N * (unsigned long long)(100u - T.trim_centre_pct) / 200ull;
+    const unsigned long long lo = skip, hi = N - skip;
+    if (tid == 0) {
+        s_qrank[0] = lo; s_qneed[0] = (N > 0 && lo > 0 && lo < N) ? 1u : 0u;
+        s_qrank[1] = hi; s_qneed[1] = (N > 0 && hi > 0 && hi < N) ? 1u : 0u;
+        const uint32_t pcts[3] = {25u, 50u, 75u};
+        for (int p = 0; p < 3; p++) {
+            const unsigned long long num = (N + 1ull) * pcts[p];
+            const unsigned long long k = num / 100ull;
+            const uint32_t rem = (uint32_t)(num % 100ull);
+            unsigned long long ra = 0, rb = 0;
+            bool nb = false;
+            if (N > 0) {
+                if (k < 1) ra = 0;
+                else if (k >= N) ra = N - 1;
+                else { ra = k - 1; rb = k; nb = T.pct_interpolate != 0 && rem != 0; }
+            }
+            s_qrank[2 + 2 * p] = ra; s_qneed[2 + 2 * p] = N > 0 ? 1u : 0u;
+            s_qrank[3 + 2 * p] = rb; s_qneed[3 + 2 * p] = nb ? 1u : 0u;
+            s_prem[p] = rem;
+        }
+    }
+    if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
+    __syncthreads();
+
+    if (N > 0 && !s_overflow) {
+        // single level: bins are the depths themselves
+        uint32_t c[kBinsPerThread];
+        uint32_t tot = 0;
+        unsigned long long tsum = 0;
+#pragma unroll
+        for (int j = 0; j < kBinsPerThread; j++) {
+            c[j] = s_cnt[tid * kBinsPerThread + j];
+            tot += c[j];
+            tsum += (unsigned long long)c[j] * (unsigned long long)(tid * kBinsPerThread + j);
+        }
+        uint32_t pre;
+        unsigned long long pre_sum;
+        block_excl_scan(tot, tsum, pre, pre_sum, s_wc, s_ws);
+#pragma unroll
+        for (int q = 0; q < kQueries; q++) {
+            if (!s_qneed[q]) continue;
+            const unsigned long long r = s_qrank[q];
+            if (r >= pre && r < (unsigned long long)pre + tot) {
+                unsigned long long run = pre, s = pre_sum;
+#pragma unroll
+                for (int j = 0; j < kBinsPerThread; j++) {
+                    const unsigned long long bin = (unsigned long long)(tid * kBinsPerThread + j);
+                    if (r < run + c[j]) { s_qval[q] = (uint32_t)bin; s_qsum[q] = s + bin * (r - run); break; }
+                    run += c[j];
+                    s += bin * c[j];
+                }
+            }
+        }
+        __syncthreads();
+    } else if (N > 0) {
+        // multi-level radix select, one descent per query
+        int bits = 32 - __clz((int)vmax);
+        int levels = (bits + kBinBits - 1) / kBinBits;
+        if (levels < 1) levels = 1;
+        for (int q = 0; q < kQueries; q++) {
+            if (!s_qneed[q]) continue;                     // uniform across the block
+            unsigned long long r = s_qrank[q];
+            unsigned long long sum_below = 0;
+            uint32_t prefix = 0;
+            for (int lv = 0; lv < levels; lv++) {
+                const int shift = kBinBits * (levels - 1 - lv);
+                for (int k = tid; k < kBins; k += kThreads) { s_cnt[k] = 0; s_sum[k] = 0; }
+                __syncthreads();
+                for (uint32_t b = b0; b < b1; b++) {
+                    const uint64_t bs = T.blk_gstart[b];
+                    const uint32_t bl = T.blk_len[b];
+                    for (uint32_t x = tid; x < bl; x += kThreads) {
+                        const uint32_t v = C.val(bs + x);
+                        const bool in = lv == 0 || (shift + kBinBits >= 32 ? true : (v >> (shift + kBinBits)) == prefix);
+                        if (in) {
+                            const uint32_t bin = (v >> shift) & (uint32_t)(kBins - 1);
+                            atomicAdd(&s_cnt[bin], 1u);
+                            atomicAdd(&s_sum[bin], (unsigned long long)v);
+                        }
+                    }
+                }
+                __syncthreads();
+                uint32_t c[kBinsPerThread];
+                unsigned long long sm[kBinsPerThread];
+                uint32_t tot = 0;
+                unsigned long long tsum = 0;
+#pragma unroll
+                for (int j = 0; j < kBinsPerThread; j++) {
+                    c[j] = s_cnt[tid * kBinsPerThread + j];
+                    sm[j] = s_sum[tid * kBinsPerThread + j];
+                    tot += c[j];
+                    tsum += sm[j];
+                }
+                uint32_t pre;
+                unsigned long long pre_sum;
+                block_excl_scan(tot, tsum, pre, pre_sum, s_wc, s_ws);
+                if (r >= pre && r < (unsigned long long)pre + tot) {
+                    unsigned long long run = pre, s = pre_sum;
+#pragma unroll
+                    for (int j = 0; j < kBinsPerThread; j++) {
+                        if (r < run + c[j]) { s_sel_bin = tid * kBinsPerThread + j; s_sel_cnt = (uint32_t)run; s_sel_sum = s; break; }
+                        run += c[j];
+                        s += sm[j];
+                    }
+                }
+                __syncthreads();
+                prefix = (prefix << kBinBits) | s_sel_bin;
+                r -= s_sel_cnt;
+                sum_below += s_sel_sum;
+                __syncthreads();
+            }
+            if (tid == 0) { s_qval[q] = prefix; s_qsum[q] = sum_below + (unsigned long long)prefix * r; }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- the row ----------------
+    if (tid == 0) {
+        double coverage = 0.0, depth = 0.0, pv[3] = {0.0, 0.0, 0.0};
+        if (N > 0) {
+            coverage = (double)nzc / (double)N;
+            const unsigned long long s_hi = hi >= N ? total : (hi == 0 ? 0ull : s_qsum[1]);
+            const unsigned long long s_lo = lo == 0 ? 0ull : (lo >= N ? total : s_qsum[0]);
+            depth = (double)(s_hi - s_lo) / (double)(hi - lo);
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const double vk = (double)s_qval[2 + 2 * p];
+                if (s_qneed[3 + 2 * p]) pv[p] = vk + ((double)s_prem[p] / 100.0) * ((double)s_qval[3 + 2 * p] - vk);
+                else pv[p] = vk;
+            }
+        }
+        const int plane = C.plane;
+        uint32_t spl = 0, spr = 0, jl = 0, jr = 0, je = 0;
+        if (C.valid) {
+            const int32_t a = T.sp_idx_start[i], b = T.sp_idx_end[i];
+            if (a >= 0) spl = plane == 2 ? T.sp_cnt[a] + T.sp_cnt[(uint64_t)T.n_sp + a] : T.sp_cnt[(uint64_t)plane * T.n_sp + a];
+            if (b >= 0) spr = plane == 2 ? T.sp_cnt[b] + T.sp_cnt[(uint64_t)T.n_sp + b] : T.sp_cnt[(uint64_t)plane * T.n_sp + b];
+            const int32_t us = T.us_idx[i], ue = T.ue_idx[i];
+            if (us >= 0) jl = plane == 2 ? T.left_cnt[us] + T.left_cnt[(uint64_t)T.n_ustart + us] : T.left_cnt[(uint64_t)plane * T.n_ustart + us];
+            if (ue >= 0) jr = plane == 2 ? T.right_cnt[ue] + T.right_cnt[(uint64_t)T.n_uend + ue] : T.right_cnt[(uint64_t)plane * T.n_uend + ue];
+            const uint64_t span = gE - gS;
+            if (span < (1ull << kJuncSpanBits) && gS < kJuncMaxGlobal && T.n_unique > 0) {
+                const uint64_t key0 = (gS << kJuncLeftShift) | (span << 1);
+                uint64_t lo_i = 0, hi_i = T.n_unique;
+                while (lo_i < hi_i) {
+                    const uint64_t mid = lo_i + ((hi_i - lo_i) >> 1);
+                    if (T.ukeys[mid] < key0) lo_i = mid + 1; else hi_i = mid;
+                }
+                for (uint64_t u = lo_i; u < T.n_unique && u < lo_i + 2 && (T.ukeys[u] >> 1) == (key0 >> 1); u++) {
+                    const int d = (int)(T.ukeys[u] & 1ull);
+                    if (plane == 2 || plane == d) je += T.ucount[u];
+                }
+            }
+        }
+        const uint32_t smax = jl > jr ? jl : jr;
+        const double den = depth + (double)smax;
+        const double irratio = den > 0.0 ? depth / den : 0.0;
+        const double sp_max = (double)(spl > spr ? spl : spr);
+        const double fl_max = flank[0] > flank[1] ? flank[0] : flank[1];
+        const double maxflank = sp_max > fl_max ? sp_max : fl_max;
+        uint32_t warn;
+        if ((double)je + depth < T.warn_lowcover_min) warn = 1;
+        else if ((double)je < T.warn_lowsplice_min) warn = 2;
+        else if ((double)je * T.warn_minor_ratio < (double)smax) warn = 3;
+        else if (maxflank > depth * T.warn_nonuniform_rel + T.warn_nonuniform_abs) warn = 4;
+        else warn = 0;
+        const uint64_t n = T.n_intron;
+        T.out_f64[0 * n + i] = coverage;
+        T.out_f64[1 * n + i] = depth;
+        T.out_f64[2 * n + i] = pv[0];
+        T.out_f64[3 * n + i] = pv[1];
+        T.out_f64[4 * n + i] = pv[2];
+        T.out_f64[5 * n + i] = flank[0];
+        T.out_f64[6 * n + i] = flank[1];
+        T.out_f64[7 * n + i] = irratio;
+        T.out_u32[0 * n + i] = spl;
+        T.out_u32[1 * n + i] = spr;
+        T.out_u32[2 * n + i] = jl;
+        T.out_u32[3 * n + i] = jr;
+        T.out_u32[4 * n + i] = je;
+        T.out_u32[5 * n + i] = warn;
+    }
+}
+
+}   // namespace
+
+void launch_intron_stats(const IntronTables& T, hipStream_t s) {
+    if (T.n_intron == 0) return;
+    hipLaunchKernelGGL(intron_stats_kernel, dim3(T.n_intron), dim3(kThreads), 0, s, T);
+}
+
+}   // namespace dev
+}   // namespace irf

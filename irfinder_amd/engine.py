@@ -1,0 +1,304 @@
+"""Python host mirror of the C ABI (include/irf.h) over libirfhip.so.
+
+The library is the product; this module only marshals.  There is no CPU
+fallback: if libirfhip.so is missing, or no HIP device is present, the calls
+fail loudly (RuntimeError / IrfError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (STATUS, Batch, IrfBatch, IrfParams, IrfReaderStats, IrfResults, IrfTiming, IRF_MEM_DEVICE,
+                   IRF_MEM_HOST, results_to_dict)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirfhip.so")
+_LIB = None
+
+
+class IrfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "IRF_E_?"), code, msg))
+        self.code = code
+
+
+def lib():
+    """Loads libirfhip.so (built in-tree by __graft_entry__.build() / make -C irfinder_amd/csrc)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libirfhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C irfinder_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.irf_params_default.argtypes = [C.POINTER(IrfParams)]
+    L.irf_params_default.restype = None
+    L.irf_ref_load_files.argtypes = [C.c_char_p] * 4 + [C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.irf_ref_load_mem.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.irf_ref_free.argtypes = [vp]
+    L.irf_ref_free.restype = None
+    for n in ("irf_ref_n_intron", "irf_ref_n_junction", "irf_ref_n_point", "irf_ref_n_roi"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = u32
+    L.irf_create.argtypes = [C.POINTER(IrfParams), vp, C.c_int, C.POINTER(vp)]
+    L.irf_destroy.argtypes = [vp]
+    L.irf_destroy.restype = None
+    L.irf_last_error.argtypes = [vp]
+    L.irf_last_error.restype = C.c_char_p
+    L.irf_chr_map_update.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32), C.c_void_p]
+    L.irf_submit_batch.argtypes = [vp, C.POINTER(IrfBatch), C.POINTER(u64)]
+    L.irf_wait.argtypes = [vp, u64]
+    L.irf_finalize.argtypes = [vp]
+    L.irf_get_results.argtypes = [vp, C.POINTER(IrfResults)]
+    L.irf_chr_name.argtypes = [vp, u32]
+    L.irf_chr_name.restype = C.c_char_p
+    L.irf_n_chr_slots.argtypes = [vp]
+    L.irf_n_chr_slots.restype = u32
+    L.irf_write_outputs.argtypes = [vp, C.c_char_p]
+    L.irf_get_depth.argtypes = [vp, u32, u32, u32, u32, C.c_void_p]
+    L.irf_reset.argtypes = [vp]
+    L.irf_export_device.argtypes = [vp, u32, C.c_void_p, C.POINTER(u64)]
+    L.irf_get_timing.argtypes = [vp, C.POINTER(IrfTiming)]
+    L.irf_reader_create.argtypes = [C.POINTER(IrfParams), C.POINTER(vp)]
+    L.irf_reader_destroy.argtypes = [vp]
+    L.irf_reader_destroy.restype = None
+    L.irf_reader_last_error.argtypes = [vp]
+    L.irf_reader_last_error.restype = C.c_char_p
+    L.irf_reader_feed.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_int]
+    L.irf_reader_header.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(u32))]
+    L.irf_reader_batch.argtypes = [vp, C.POINTER(IrfBatch)]
+    L.irf_reader_clear_batch.argtypes = [vp]
+    L.irf_reader_clear_batch.restype = None
+    L.irf_reader_finish.argtypes = [vp]
+    L.irf_reader_get_stats.argtypes = [vp, C.POINTER(IrfReaderStats)]
+    L.irf_cigar2block.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, u32, C.POINTER(u32), C.POINTER(u32)]
+    _LIB = L
+    return L
+
+
+def default_params(**over):
+    p = IrfParams()
+    lib().irf_params_default(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def cigar2block(words):
+    w = np.ascontiguousarray(words, np.uint32)
+    starts = np.zeros(max(len(w), 1), np.uint32)
+    lens = np.zeros(max(len(w), 1), np.uint32)
+    nb, gl = C.c_uint32(), C.c_uint32()
+    rc = lib().irf_cigar2block(w.ctypes.data, len(w), starts.ctypes.data, lens.ctypes.data, len(starts), C.byref(nb),
+                               C.byref(gl))
+    if rc != 0:
+        raise IrfError(rc, "irf_cigar2block")
+    return starts[:nb.value].tolist(), lens[:nb.value].tolist(), gl.value
+
+
+class RefTables:
+    """The four reference files (ref-cover.bed, ref-sj.ref, ref-read-continues.ref, ref-ROI.bed)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_texts(cls, texts):
+        L = lib()
+        bufs = [t.encode() if isinstance(t, str) else bytes(t) for t in texts]
+        arr = (C.c_char_p * 4)(*bufs)
+        lens = (C.c_size_t * 4)(*[len(b) for b in bufs])
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = L.irf_ref_load_mem(arr, lens, C.byref(h), err, 256)
+        if rc != 0:
+            raise IrfError(rc, err.value.decode())
+        return cls(h)
+
+    @classmethod
+    def from_files(cls, cover, sj, read_continues, roi):
+        L = lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = L.irf_ref_load_files(cover.encode(), sj.encode(), read_continues.encode(), roi.encode(), C.byref(h), err, 256)
+        if rc != 0:
+            raise IrfError(rc, err.value.decode())
+        return cls(h)
+
+    def counts(self):
+        L = lib()
+        return dict(n_intron=L.irf_ref_n_intron(self.h), n_junction=L.irf_ref_n_junction(self.h),
+                    n_point=L.irf_ref_n_point(self.h), n_roi=L.irf_ref_n_roi(self.h))
+
+    def close(self):
+        if self.h:
+            lib().irf_ref_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Reader:
+    """Host BAM reader (BAM2blocks replacement): bytes in, SoA fragment batches out."""
+
+    def __init__(self, params=None):
+        self.L = lib()
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        rc = self.L.irf_reader_create(C.byref(self.params), C.byref(self.h))
+        if rc != 0:
+            raise IrfError(rc, "irf_reader_create")
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise IrfError(rc, self.L.irf_reader_last_error(self.h).decode())
+
+    def feed(self, data, bgzf=False):
+        if isinstance(data, np.ndarray):
+            ptr, n = data.ctypes.data, data.nbytes
+        else:
+            data = bytes(data)
+            ptr, n = C.cast(C.c_char_p(data), C.c_void_p), len(data)
+        self._chk(self.L.irf_reader_feed(self.h, ptr, n, 1 if bgzf else 0))
+
+    def finish(self):
+        self._chk(self.L.irf_reader_finish(self.h))
+
+    def header(self):
+        names = C.POINTER(C.c_char_p)()
+        lens = C.POINTER(C.c_uint32)()
+        n = self.L.irf_reader_header(self.h, C.byref(names), C.byref(lens))
+        if n < 0:
+            raise IrfError(n, "BAM header not complete")
+        return [names[i].decode() for i in range(n)], [int(lens[i]) for i in range(n)]
+
+    def batch_struct(self):
+        b = IrfBatch()
+        self._chk(self.L.irf_reader_batch(self.h, C.byref(b)))
+        return b
+
+    def take_batch(self):
+        """Copy of the fragments assembled so far; clears the reader's buffers."""
+        out = Batch.from_struct(self.batch_struct())
+        self.L.irf_reader_clear_batch(self.h)
+        return out
+
+    def stats(self):
+        rs = IrfReaderStats()
+        self._chk(self.L.irf_reader_get_stats(self.h, C.byref(rs)))
+        return {n: int(getattr(rs, n)) for n, _ in IrfReaderStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.L.irf_reader_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One irf_ctx: mirrors ReadBlockProcessor's ChrMapUpdate / ProcessBlocks (batched) + the end-of-run writers."""
+
+    def __init__(self, ref, params=None, device=0):
+        self.L = lib()
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        rc = self.L.irf_create(C.byref(self.params), ref.h, int(device), C.byref(self.h))
+        if rc != 0:
+            raise IrfError(rc, "irf_create failed (no HIP device, or bad parameters)")
+        self.device = device
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise IrfError(rc, self.L.irf_last_error(self.h).decode())
+
+    def chr_map_update(self, names, lens, owned=None):
+        n = len(names)
+        arr = (C.c_char_p * n)(*[s.encode() for s in names])
+        la = (C.c_uint32 * n)(*[int(x) for x in lens])
+        ow = None
+        if owned is not None:
+            self._owned = np.ascontiguousarray(owned, np.uint8)
+            ow = self._owned.ctypes.data
+        self._chk(self.L.irf_chr_map_update(self.h, n, arr, la, ow))
+
+    def submit(self, batch):
+        """batch: _abi.Batch (host) or an IrfBatch struct (host or device pointers)."""
+        b = batch.struct() if isinstance(batch, Batch) else batch
+        bid = C.c_uint64()
+        self._chk(self.L.irf_submit_batch(self.h, C.byref(b), C.byref(bid)))
+        return bid.value
+
+    def wait(self, bid):
+        self._chk(self.L.irf_wait(self.h, bid))
+
+    def process(self, batch):
+        bid = self.submit(batch)
+        self.wait(bid)
+
+    def finalize(self):
+        self._chk(self.L.irf_finalize(self.h))
+
+    def reset(self):
+        self._chk(self.L.irf_reset(self.h))
+
+    def results(self):
+        r = IrfResults()
+        self._chk(self.L.irf_get_results(self.h, C.byref(r)))
+        d = results_to_dict(r)
+        d["chr_names"] = [self.L.irf_chr_name(self.h, i).decode() for i in range(self.L.irf_n_chr_slots(self.h))]
+        return d
+
+    def write_outputs(self, outdir):
+        self._chk(self.L.irf_write_outputs(self.h, outdir.encode()))
+
+    def depth(self, chr_id, start, end, plane):
+        out = np.zeros(end - start, np.uint32)
+        self._chk(self.L.irf_get_depth(self.h, chr_id, start, end, plane, out.ctypes.data))
+        return out
+
+    def timing(self):
+        t = IrfTiming()
+        self._chk(self.L.irf_get_timing(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in IrfTiming._fields_ if n != "reserved"}
+
+    def export_size(self, what):
+        n = C.c_uint64()
+        self._chk(self.L.irf_export_device(self.h, what, None, C.byref(n)))
+        return n.value
+
+    def export_device(self, what, dst_ptr):
+        n = C.c_uint64()
+        self._chk(self.L.irf_export_device(self.h, what, C.c_void_p(dst_ptr), C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.h:
+            self.L.irf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_batch(tensors, n_frag, n_blk):
+    """irf_batch over device-resident arrays (objects with .data_ptr(), e.g. torch tensors), keyed like Batch.FIELDS."""
+    b = IrfBatch()
+    b.n_frag, b.n_blk = int(n_frag), int(n_blk)
+    for name, _ in Batch.FIELDS:
+        setattr(b, name, tensors[name].data_ptr())
+    b.mem_kind = IRF_MEM_DEVICE
+    return b

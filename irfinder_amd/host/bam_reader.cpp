@@ -1,0 +1,257 @@
+// bam_reader.cpp — see bam_reader.h
+#include "bam_reader.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace irf {
+
+namespace {
+inline uint32_t le32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t le16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+const uint32_t kMaxBlockSize = 1u << 28;
+}   // namespace
+
+// ⟨upstream⟩ BAM2blocks::cigar2block.  M,D,=,X extend the open block; N closes
+// it and moves the origin; I,S,H,P are ignored.
+uint32_t cigar_to_blocks(uint32_t pos, const uint32_t* cigar, uint32_t n_cigar, std::vector<BlockSpan>& out) {
+    out.clear();
+    uint32_t origin = pos, run = 0;
+    for (uint32_t i = 0; i < n_cigar; i++) {
+        const uint32_t op = cigar[i] & 0xfu, l = cigar[i] >> 4;
+        if (op == 0 || op == 2 || op == 7 || op == 8) {
+            run += l;
+        } else if (op == 3) {
+            if (run) out.push_back(BlockSpan{origin, run});
+            origin += run + l;
+            run = 0;
+        }
+    }
+    if (run) out.push_back(BlockSpan{origin, run});
+    return origin + run;
+}
+
+BamReader::BamReader(const irf_params& p) : P(p) {
+    memset(&stats, 0, sizeof stats);
+    z_stream* zs = new z_stream();
+    memset(zs, 0, sizeof *zs);
+    inflateInit2(zs, -15);
+    zs_ = zs;
+}
+
+BamReader::~BamReader() {
+    z_stream* zs = (z_stream*)zs_;
+    inflateEnd(zs);
+    delete zs;
+}
+
+int BamReader::feed(const uint8_t* data, size_t len, bool bgzf) {
+    if (!error.empty()) return IRF_E_PARSE;
+    if (bgzf) {
+        if (zoff_ > 0 && zoff_ == zbuf_.size()) { zbuf_.clear(); zoff_ = 0; }
+        zbuf_.insert(zbuf_.end(), data, data + len);
+        int rc = inflate_blocks();
+        if (rc != 0) return rc;
+    } else {
+        if (roff_ > 0 && roff_ == raw_.size()) { raw_.clear(); roff_ = 0; }
+        raw_.insert(raw_.end(), data, data + len);
+    }
+    return parse_raw();
+}
+
+// BGZF (SAM spec §4.1): gzip members with a 'BC' extra subfield carrying BSIZE.
+int BamReader::inflate_blocks() {
+    z_stream* zs = (z_stream*)zs_;
+    while (true) {
+        size_t avail = zbuf_.size() - zoff_;
+        if (avail < 18) break;
+        const uint8_t* h = zbuf_.data() + zoff_;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { error = "BGZF: bad member header"; return IRF_E_PARSE; }
+        uint32_t xlen = le16(h + 10);
+        if (avail < 12 + (size_t)xlen) break;
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t* sf = h + 12 + x;
+            uint32_t slen = le16(sf + 2);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = le16(sf + 4); found = true; }
+            x += 4 + slen;
+        }
+        if (!found) { error = "BGZF: missing BC subfield"; return IRF_E_PARSE; }
+        size_t total = (size_t)bsize + 1;
+        if (total < 12 + (size_t)xlen + 8) { error = "BGZF: bad BSIZE"; return IRF_E_PARSE; }
+        if (avail < total) break;
+        size_t clen = total - 12 - xlen - 8;
+        uint32_t crc = le32(h + total - 8), isize = le32(h + total - 4);
+        if (isize > 65536) { error = "BGZF: ISIZE > 64 KiB"; return IRF_E_PARSE; }
+        if (isize) {
+            if (roff_ > (1u << 20) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
+            size_t at = raw_.size();
+            raw_.resize(at + isize);
+            inflateReset(zs);
+            zs->next_in = const_cast<Bytef*>(h + 12 + xlen);
+            zs->avail_in = (uInt)clen;
+            zs->next_out = raw_.data() + at;
+            zs->avail_out = isize;
+            int zr = inflate(zs, Z_FINISH);
+            if (zr != Z_STREAM_END || zs->avail_out != 0) { raw_.resize(at); error = "BGZF: inflate failed"; return IRF_E_PARSE; }
+            if ((uint32_t)crc32(0L, raw_.data() + at, isize) != crc) { raw_.resize(at); error = "BGZF: CRC mismatch"; return IRF_E_PARSE; }
+        }
+        zoff_ += total;
+    }
+    if (zoff_ > (1u << 20) && zoff_ * 2 > zbuf_.size()) { zbuf_.erase(zbuf_.begin(), zbuf_.begin() + (ptrdiff_t)zoff_); zoff_ = 0; }
+    return 0;
+}
+
+// ⟨upstream⟩ BAM2blocks::readBamHeader
+int BamReader::parse_header(bool& need_more) {
+    need_more = true;
+    const uint8_t* p = raw_.data() + roff_;
+    size_t avail = raw_.size() - roff_, o = 0;
+    if (avail < 12) return 0;
+    if (memcmp(p, "BAM\1", 4) != 0) { error = "BAM: bad magic"; return IRF_E_PARSE; }
+    int32_t l_text = (int32_t)le32(p + 4);
+    if (l_text < 0) { error = "BAM: negative l_text"; return IRF_E_PARSE; }
+    o = 8 + (size_t)l_text;
+    if (avail < o + 4) return 0;
+    int32_t n_ref = (int32_t)le32(p + o);
+    if (n_ref < 0) { error = "BAM: negative n_ref"; return IRF_E_PARSE; }
+    o += 4;
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (avail < o + 4) return 0;
+        int32_t l_name = (int32_t)le32(p + o);
+        if (l_name <= 0 || l_name > (1 << 20)) { error = "BAM: bad l_name"; return IRF_E_PARSE; }
+        o += 4;
+        if (avail < o + (size_t)l_name + 4) return 0;
+        names.emplace_back((const char*)p + o, (size_t)l_name - 1);
+        o += (size_t)l_name;
+        lens.push_back(le32(p + o));
+        o += 4;
+    }
+    chr_names.swap(names);
+    chr_lens.swap(lens);
+    chr_name_ptrs.clear();
+    for (auto& s : chr_names) chr_name_ptrs.push_back(s.c_str());
+    roff_ += o;
+    header_done_ = true;
+    need_more = false;
+    return 0;
+}
+
+// ⟨upstream⟩ BAM2blocks::processAll — record loop with adjacent-mate pairing
+int BamReader::parse_raw() {
+    if (!header_done_) {
+        bool need_more;
+        int rc = parse_header(need_more);
+        if (rc != 0) return rc;
+        if (need_more) return 0;
+    }
+    while (true) {
+        size_t avail = raw_.size() - roff_;
+        if (avail < 4) break;
+        const uint8_t* p = raw_.data() + roff_;
+        uint32_t block_size = le32(p);
+        if (block_size < 32 || block_size > kMaxBlockSize) { error = "BAM: bad block_size"; return IRF_E_PARSE; }
+        if (avail < 4 + (size_t)block_size) break;
+        bool bad = false;
+        on_record(p + 4, block_size, bad);
+        if (bad) return IRF_E_PARSE;
+        roff_ += 4 + (size_t)block_size;
+    }
+    if (roff_ > (1u << 22) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
+    return 0;
+}
+
+void BamReader::on_record(const uint8_t* p, uint32_t block_size, bool& bad) {
+    Rec& r = cur_;
+    r.ref_id = (int32_t)le32(p);
+    r.pos = (int32_t)le32(p + 4);
+    uint32_t l_read_name = p[8];
+    uint32_t n_cigar = le16(p + 12);
+    r.flag = le16(p + 14);
+    int32_t l_seq = (int32_t)le32(p + 16);
+    if (32 + (size_t)l_read_name + 4 * (size_t)n_cigar > block_size) { error = "BAM: record fields overrun block_size"; bad = true; return; }
+    r.cigar.resize(n_cigar);
+    if (n_cigar) memcpy(r.cigar.data(), p + 32 + l_read_name, 4 * (size_t)n_cigar);
+    stats.n_records++;
+    if (l_seq > 0) stats.n_nucleotides += (uint64_t)l_seq;
+
+    const int32_t n_ref = (int32_t)chr_names.size();
+    if (have_pending_) {
+        have_pending_ = false;
+        const Rec& a = pending_;
+        const Rec& b = r;
+        if ((a.flag | b.flag) & P.skip_flag_mask) { stats.n_skipped += 2; return; }
+        if (a.ref_id != b.ref_id || a.ref_id < 0 || a.ref_id >= n_ref || a.pos < 0 || b.pos < 0) { stats.n_error += 2; return; }
+        if (a.pos <= b.pos) emit_pair(a, b); else emit_pair(b, a);
+        return;
+    }
+    if (r.flag & 0x1) {           // paired: the NEXT record is taken as the mate
+        std::swap(pending_, cur_);
+        have_pending_ = true;
+        return;
+    }
+    if (r.flag & P.skip_flag_mask) { stats.n_skipped++; return; }
+    if (r.ref_id < 0 || r.ref_id >= n_ref || r.pos < 0) { stats.n_error++; return; }
+    emit_single(r);
+}
+
+int BamReader::finish() {
+    if (!error.empty()) return IRF_E_PARSE;
+    if (zoff_ != zbuf_.size()) { error = "BGZF: truncated block at end of input"; return IRF_E_PARSE; }
+    if (!header_done_) { error = "BAM: truncated header"; return IRF_E_PARSE; }
+    if (roff_ != raw_.size()) { error = "BAM: truncated record at end of input"; return IRF_E_PARSE; }
+    if (have_pending_) { have_pending_ = false; stats.n_error++; }
+    return 0;
+}
+
+// ⟨upstream⟩ BAM2blocks::processSingle
+void BamReader::emit_single(const Rec& r) {
+    uint32_t end = cigar_to_blocks((uint32_t)r.pos, r.cigar.data(), (uint32_t)r.cigar.size(), b1_);
+    if (b1_.empty()) { stats.n_error++; return; }
+    batch.add((uint32_t)r.ref_id, !(r.flag & 0x10), (uint32_t)r.pos, end, b1_.data(), b1_.size(), nullptr, 0, false);
+    stats.n_singles++;
+}
+
+// ⟨upstream⟩ BAM2blocks::processPair.  a is the left mate (a.pos <= b.pos).
+void BamReader::emit_pair(const Rec& a, const Rec& b) {
+    const uint32_t pos1 = (uint32_t)a.pos, pos2 = (uint32_t)b.pos;
+    const uint32_t e1 = cigar_to_blocks(pos1, a.cigar.data(), (uint32_t)a.cigar.size(), b1_);
+    const uint32_t e2 = cigar_to_blocks(pos2, b.cigar.data(), (uint32_t)b.cigar.size(), b2_);
+    if (b1_.empty() || b2_.empty()) { stats.n_error += 2; return; }
+    // strand of read 1, read off the left record
+    const bool dir = (a.flag & 0x40) ? !(a.flag & 0x10) : !(a.flag & 0x20);
+    const uint32_t chr = (uint32_t)a.ref_id;
+    const bool is_long = P.pair_long_inclusive ? (e1 <= pos2) : (e1 < pos2);
+    stats.n_pairs++;
+    if (!is_long) {
+        const bool is_short = P.pair_short_inclusive ? (e1 >= e2) : (e1 > e2);
+        if (is_short) {                      // read 2 inside read 1: read-1 blocks only
+            stats.n_pairs_short++;
+            batch.add(chr, dir, pos1, e1, b1_.data(), b1_.size(), nullptr, 0, false);
+            return;
+        }
+        // Intersect: extend the read-1 block that holds pos2 by read 2's first block, then append the rest of read 2
+        for (size_t i = 0; i < b1_.size(); i++) {
+            const uint32_t bs = b1_[i].start, be = bs + b1_[i].len;
+            if (bs <= pos2 && pos2 <= be) {
+                merged_.assign(b1_.begin(), b1_.begin() + (ptrdiff_t)i + 1);
+                merged_[i].len = pos2 - bs + b2_[0].len;
+                merged_.insert(merged_.end(), b2_.begin() + 1, b2_.end());
+                stats.n_pairs_intersect++;
+                batch.add(chr, dir, pos1, std::max(e1, e2), merged_.data(), merged_.size(), nullptr, 0, false);
+                return;
+            }
+        }
+        // pos2 falls in an N gap of read 1 (OQ-3): handled as two separate reads
+    }
+    stats.n_pairs_long++;
+    batch.add(chr, dir, pos1, std::max(e1, e2), b1_.data(), b1_.size(), b2_.data(), b2_.size(), true);
+}
+
+}   // namespace irf

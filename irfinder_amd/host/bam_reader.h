@@ -1,0 +1,62 @@
+// bam_reader.h — streaming BAM reader + fragment assembler.
+//
+// Replaces ⟨upstream⟩ BAM2blocks.{h,cpp} (readBamHeader, processAll,
+// processPair, processSingle, cigar2block) for callers that do not bring their
+// own reader.  Upstream pulls from an std::istream and calls back once per
+// fragment; this reader is push-driven (feed any chunking of raw or BGZF
+// bytes) and assembles fragments straight into SoA batches for the device.
+// Fragment semantics: SURVEY App. B.1 (recalled; OQ-1/2/3 are irf_params).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/irf.h"
+#include "soa_batch.h"
+
+namespace irf {
+
+// cigar words -> absolute aligned blocks; returns the reference end of the read
+uint32_t cigar_to_blocks(uint32_t pos, const uint32_t* cigar, uint32_t n_cigar, std::vector<BlockSpan>& out);
+
+class BamReader {
+public:
+    explicit BamReader(const irf_params& p);
+    ~BamReader();
+    int feed(const uint8_t* data, size_t len, bool bgzf);
+    int finish();
+    bool header_done() const { return header_done_; }
+
+    std::vector<std::string> chr_names;
+    std::vector<uint32_t> chr_lens;
+    std::vector<const char*> chr_name_ptrs;
+    BatchBuilder batch;
+    irf_reader_stats stats;
+    std::string error;
+
+private:
+    struct Rec {
+        int32_t ref_id = -1, pos = 0;
+        uint16_t flag = 0;
+        std::vector<uint32_t> cigar;
+    };
+    int inflate_blocks();
+    int parse_raw();
+    int parse_header(bool& need_more);
+    void on_record(const uint8_t* p, uint32_t block_size, bool& bad);
+    void emit_single(const Rec& r);
+    void emit_pair(const Rec& a, const Rec& b);
+
+    irf_params P;
+    std::vector<uint8_t> zbuf_;
+    size_t zoff_ = 0;
+    std::vector<uint8_t> raw_;
+    size_t roff_ = 0;
+    bool header_done_ = false;
+    bool have_pending_ = false;
+    Rec pending_, cur_;
+    std::vector<BlockSpan> b1_, b2_, merged_;
+    void* zs_ = nullptr;
+};
+
+}   // namespace irf

@@ -1,0 +1,140 @@
+"""Host logic of the product (no GPU): BAM reader / fragment assembly vs the oracle's reader, C-ABI surface."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from irfinder_amd import engine
+from irfinder_amd._abi import IrfParams
+from irfinder_amd.synth.bam import bgzf_compress, records_to_bam
+from util import small_world
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "irf.h")).read()
+    declared = set(re.findall(r"\b(irf_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.check_output(["nm", "-D", engine.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (irf_\w+)", out))
+    assert declared and declared <= exported, sorted(declared - exported)
+    L = engine.lib()
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_params_defaults_match_oracle_and_struct_size():
+    a, b = engine.default_params(), orc.default_params()
+    assert a.struct_size == C.sizeof(IrfParams) == b.struct_size
+    for f, _ in IrfParams._fields_:
+        assert getattr(a, f) == getattr(b, f), f
+
+
+def test_cigar2block_kat1_product():
+    for cig, exp in [("50M1000N50M", ([0, 1050], [50, 50], 1100)), ("5S45M2D5M100N3I50M", ([0, 152], [52, 50], 202)),
+                     ("10M100N200N10M", ([0, 310], [10, 10], 320)), ("10S5I", ([], [], 0)), ("3=2X5M", ([0], [10], 10))]:
+        assert engine.cigar2block(orc.cigar_words(cig)) == exp
+        assert orc.cigar2block(cig) == exp
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_reader_matches_oracle_on_synthetic_bam(stranded):
+    ann, sim = small_world(n_pairs=0, stranded=stranded, seed=11)
+    bam = sim.bam(0, 30000)
+    ob, ost, rc = orc.bam_to_batch(bam)
+    assert rc == 0
+    r = engine.Reader()
+    r.feed(bam)
+    r.finish()
+    assert r.header() == (ann.chr_names, ann.chr_lens)
+    pb = r.take_batch()
+    assert pb.equals(ob)
+    assert r.stats() == ost
+    assert ost["n_pairs_intersect"] > 0 and ost["n_pairs_long"] > 0 and ost["n_singles"] > 0
+
+
+def test_reader_chunked_and_bgzf():
+    ann, sim = small_world(seed=5)
+    bam = sim.bam(100, 5000)
+    ref, _, _ = orc.bam_to_batch(bam)
+    rng = np.random.default_rng(0)
+    # raw stream in ragged chunks (including 1-byte pieces across the header)
+    r = engine.Reader()
+    pos = 0
+    while pos < len(bam):
+        n = int(rng.integers(1, 4000)) if pos > 64 else 1
+        r.feed(bam[pos:pos + n])
+        pos += n
+    r.finish()
+    assert r.take_batch().equals(ref)
+    # BGZF, fed in ragged chunks
+    z = bgzf_compress(bam, block=20000)
+    r = engine.Reader()
+    pos = 0
+    while pos < len(z):
+        n = int(rng.integers(1, 30000))
+        r.feed(z[pos:pos + n], bgzf=True)
+        pos += n
+    r.finish()
+    assert r.take_batch().equals(ref)
+
+
+def test_reader_fault_injection():
+    ann, sim = small_world(seed=5)
+    bam = sim.bam(0, 200)
+    r = engine.Reader()
+    r.feed(bam[:-5])
+    with pytest.raises(engine.IrfError):
+        r.finish()                                  # truncated record
+    r = engine.Reader()
+    with pytest.raises(engine.IrfError):
+        r.feed(b"BAX\1" + bam[4:])                  # bad magic
+    z = bytearray(bgzf_compress(bam, block=4000))
+    z[40] ^= 0xff                                   # corrupt deflate payload
+    r = engine.Reader()
+    with pytest.raises(engine.IrfError):
+        r.feed(bytes(z), bgzf=True)
+        r.finish()
+    r = engine.Reader()
+    r.feed(bgzf_compress(bam)[:-40], bgzf=True)     # truncated BGZF block
+    with pytest.raises(engine.IrfError):
+        r.finish()
+
+
+def test_reader_edge_records():
+    chrs, lens = ["c1", "c2"], [10000, 5000]
+    recs = [dict(ref_id=0, pos=1, flag=0x41, cigar="10M"), dict(ref_id=1, pos=1, flag=0x81, cigar="10M"),     # different refs
+            dict(ref_id=0, pos=1, flag=0x45, cigar="10M"), dict(ref_id=0, pos=1, flag=0x81, cigar="10M"),     # unmapped mate
+            dict(ref_id=0, pos=5, flag=0x0, cigar="4S"),                                                    # no aligned block
+            dict(ref_id=-1, pos=-1, flag=0x0, cigar="10M"),                                                  # no reference
+            dict(ref_id=0, pos=100, flag=0x61, cigar="20M300N20M"), dict(ref_id=0, pos=90, flag=0x91, cigar="15M"),
+            dict(ref_id=0, pos=1, flag=0x41, cigar="10M")]                                                   # dangling mate
+    bam = records_to_bam(chrs, lens, recs)
+    ob, ost, rc = orc.bam_to_batch(bam)
+    r = engine.Reader()
+    r.feed(bam)
+    r.finish()
+    assert r.take_batch().equals(ob) and r.stats() == ost
+    assert ost["n_error"] == 2 + 1 + 1 + 1 and ost["n_skipped"] == 2 and ob.n_frag == 1
+    # empty BAM (header only)
+    r = engine.Reader()
+    r.feed(records_to_bam(chrs, lens, []))
+    r.finish()
+    assert r.take_batch().n_frag == 0
+
+
+def test_oq_switches_reach_the_reader():
+    chrs, lens = ["c1"], [10000]
+    recs = [dict(ref_id=0, pos=100, flag=0x63, cigar="50M"), dict(ref_id=0, pos=150, flag=0x93, cigar="50M"),
+            dict(ref_id=0, pos=100, flag=0x63 | 0x100, cigar="50M"), dict(ref_id=0, pos=400, flag=0x93, cigar="50M")]
+    bam = records_to_bam(chrs, lens, recs)
+    for over in ({}, {"pair_long_inclusive": 1}, {"skip_flag_mask": 0x104}, {"pair_short_inclusive": 0}):
+        ob, ost, _ = orc.bam_to_batch(bam, orc.default_params(**over))
+        r = engine.Reader(engine.default_params(**over))
+        r.feed(bam)
+        r.finish()
+        assert r.take_batch().equals(ob) and r.stats() == ost, over
