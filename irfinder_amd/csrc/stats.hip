@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
             coverage = (double)nzc / (double)N;
             const unsigned long long s_hi = hi >= N ? total : (hi == 0 ? 0ull : s_qsum[1]);
             const unsigned long long s_lo = lo == 0 ? 0ull : (lo >= N ? total : s_qsum[0]);
-            depth = (double)(s_hi - s_lo) / (double)(hi - lo);
+            depth = hi > lo ? (double)(s_hi - s_lo) / (double)(hi - lo) : 0.0;
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const double vk = (double)s_qval[2 + 2 * p];

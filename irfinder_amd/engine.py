@@ -23,6 +23,24 @@ class IrfError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one process
+    do not both see the GPU, so when torch is installed its copy is mapped first and libirfhip.so binds to it (the
+    loader matches the SONAME).  Set IRF_HIP_RUNTIME=system to keep /opt/rocm's runtime (processes without torch)."""
+    if os.environ.get("IRF_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Loads libirfhip.so (built in-tree by __graft_entry__.build() / make -C irfinder_amd/csrc)."""
     global _LIB
@@ -31,6 +49,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libirfhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C irfinder_amd/csrc`" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
     L.irf_params_default.argtypes = [C.POINTER(IrfParams)]

@@ -389,6 +389,7 @@ static double trimmedMeanFromHist(const std::map<uint, uint>& hist, uint centreP
     if (n == 0) return 0.0;
     unsigned long skip = (unsigned long)((unsigned long long)n * (100 - centrePct) / 200);   /* OQ-8 */
     unsigned long lo = skip, hi = n - skip;      /* keep 0-based ranks [lo,hi) */
+    if (hi <= lo) return 0.0;                    /* centre 0 %: nothing kept */
     unsigned long long sum = 0;
     unsigned long c = 0;
     for (auto& kv : hist) {
