@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py — read pairs/s from device-resident SoA fragment batches to the IR table (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = the whole counting job over one synthetic sample: zero the counters, count every fragment (fused count
+kernel), sort-reduce the junctions, scan the depth planes, per-intron statistics, IR table copied to the host
+(rank 0; after the RCCL collection when N > 1).  Inputs are resident in HBM when the clock starts.
+
+Workload at N=1 = BASELINE.json configs[1]: 50 M simulated 2x150 bp pairs, full GRCh38-sized synthetic GENCODE-like
+reference, unstranded, coordinate-sorted.  At N>1 the reference is sharded by chromosome (LPT) and every rank holds
+50 M pairs on its own chromosomes (weak scaling; configs[3] at N=8 = 400 M pairs).  No collective on the data path;
+the result tables are collected on rank 0 over RCCL inside the timed region.
+
+The JSON line carries `roofline` (dominant kernel, algorithmic bytes / HIP-event time vs 8 TB/s HBM) and
+`cpu_baseline` (the CPU oracle — this repo's single-threaded C++ restatement of IRFinder's engine, NOT the upstream
+binary, which is not available — on a bounded sample of the same workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=50_000_000, help="pairs per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--stranded", type=int, default=0)
+    ap.add_argument("--order", choices=["sorted", "random"], default="sorted")
+    ap.add_argument("--genome", choices=["grch38", "chr22", "toy"], default="grch38")
+    ap.add_argument("--cpu-pairs", type=int, default=2_000_000, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "8")))
+    ap.add_argument("--no-decode-bench", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from irfinder_amd import distributed as irfdist
+    from irfinder_amd import engine
+    from irfinder_amd._abi import (COL_IR_NONDIR_F64, COL_IR_NONDIR_U32, COL_IR_DIR_F64, COL_IR_DIR_U32, COL_JUNC_KEYS,
+                                   COL_JUNC_COUNTS, COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, Batch)
+    from irfinder_amd.synth import world as synth_world
+    from irfinder_amd.synth.annotation import GRCH38, make_annotation, small_chroms
+    from irfinder_amd.synth.reads import ReadSimulator
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---------------- workload ----------------
+    cfg_idx = 2 if args.stranded else 1
+    seed = 20240807 + cfg_idx
+    chroms = {"grch38": GRCH38, "chr22": [GRCH38[21]], "toy": small_chroms(3, 400_000)}[args.genome]
+    t0 = time.time()
+    ann = make_annotation(chroms, seed=seed)
+    names, lens = ann.chr_names, ann.chr_lens
+    log("annotation: %d introns, %d junctions, %d points, %d ROIs, %.3g measured bases (%.1fs)" % (
+        ann.n_intron, ann.n_junction, ann.n_point, ann.n_roi, ann.measured_bases, time.time() - t0))
+    masks = irfdist.shard_chromosomes(lens, world)
+    owned = masks[rank]
+    # this rank's simulator draws only from its own chromosomes
+    import copy
+    ann_r = copy.copy(ann)
+    if world > 1:
+        ann_r.tx_weight = ann.tx_weight * owned[ann.tx_chr].astype(np.float64)
+        ann_r.chr_lens = list(ann.chr_lens)
+    sim = ReadSimulator(ann_r, read_len=args.read_len, stranded=bool(args.stranded), seed=seed + 1000 * rank)
+    if world > 1:   # noise reads: only on owned chromosomes
+        cl = np.asarray(lens, np.float64) * owned
+        sim._keep.append(np.ascontiguousarray(np.cumsum(cl) / cl.sum()))
+        sim.model.chr_cdf = sim._keep[-1].ctypes.data
+    t0 = time.time()
+    batches, rstats = synth_world.generate_batches(sim, 0, args.pairs, chunk=500_000, threads=args.threads)
+    gen_s = time.time() - t0
+    host = synth_world.concat_batches(batches)
+    del batches
+    if args.order == "sorted":
+        host = synth_world.sort_by_coordinate(host)
+    n_frag, n_blk = host.n_frag, host.n_blk
+    log("rank %d: %d fragments, %d blocks (%.2f/frag) generated+assembled in %.1fs (%.2f M pairs/s host, %d threads); "
+        "classes short/intersect/long = %d/%d/%d" % (rank, n_frag, n_blk, n_blk / max(n_frag, 1), gen_s,
+                                                     args.pairs / gen_s / 1e6, args.threads, rstats["n_pairs_short"],
+                                                     rstats["n_pairs_intersect"], rstats["n_pairs_long"]))
+    t0 = time.time()
+    dten = {n: torch.from_numpy(getattr(host, n)).to(dev) for n, _ in Batch.FIELDS}
+    torch.cuda.synchronize()
+    h2d_s = time.time() - t0
+    in_bytes = sum(getattr(host, n).nbytes for n, _ in Batch.FIELDS)
+    dbatch = engine.device_batch(dten, n_frag, n_blk)
+
+    ref = engine.RefTables.from_texts(ann.ref_texts())
+    eng = engine.Engine(ref, device=local_rank)
+    eng.chr_map_update(names, lens, owned if world > 1 else None)
+
+    # introns this rank owns (for the masked reduce)
+    name_to_idx = {n: i for i, n in enumerate(names)}
+    in_chr = np.array([name_to_idx[l.split("\t", 1)[0]] for l in ann.cover_bed.splitlines()], np.int64)
+    intron_owned = torch.from_numpy(owned[in_chr].astype(np.int64)).to(dev)
+    n_in = len(in_chr)
+
+    out = {}
+
+    def export(col, shape, dtype):
+        n = eng.export_size(col)
+        t = torch.empty(n, dtype=dtype, device=dev)
+        if n:
+            eng.export_device(col, t.data_ptr())
+        return t.view(*shape) if shape else t
+
+    def step():
+        eng.reset()
+        eng.submit(dbatch)
+        eng.finalize()
+        tabs = {
+            "ir_f64": export(COL_IR_NONDIR_F64, (8, n_in), torch.float64),
+            "ir_u32": export(COL_IR_NONDIR_U32, (6, n_in), torch.int32),
+            "sp_cnt": export(COL_SP_CNT, None, torch.int32),
+            "roi_cnt": export(COL_ROI_CNT, None, torch.int32),
+            "chr_cnt": export(COL_CHR_CNT, None, torch.int32),
+            "junc_keys": export(COL_JUNC_KEYS, None, torch.int64),
+            "junc_counts": export(COL_JUNC_COUNTS, None, torch.int32),
+        }
+        if eng.export_size(COL_IR_DIR_F64):
+            tabs["ir_dir_f64"] = export(COL_IR_DIR_F64, (8, n_in), torch.float64)
+            tabs["ir_dir_u32"] = export(COL_IR_DIR_U32, (6, n_in), torch.int32)
+        if world > 1:
+            irfdist.mask_unowned_rows(tabs["ir_f64"], tabs["ir_u32"], intron_owned)
+            if "ir_dir_f64" in tabs:
+                irfdist.mask_unowned_rows(tabs["ir_dir_f64"], tabs["ir_dir_u32"], intron_owned)
+            got = irfdist.gather_tables(tabs, dist)
+        else:
+            got = irfdist.gather_tables(tabs, None)
+        if rank == 0:
+            out["ir_f64"] = got["ir_f64"].cpu()
+            out["ir_u32"] = got["ir_u32"].cpu()
+            out["n_junc"] = sum(int(k.numel()) for k in got["junc_keys"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kt = {"count_ms": 0.0, "scan_ms": 0.0, "stats_ms": 0.0, "junction_ms": 0.0}
+    for _ in range(args.steps):
+        step()
+        tm = eng.timing()
+        for k in kt:
+            kt[k] += tm[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / max(args.steps, 1) * 1e3
+    value = world * args.pairs / (dt / max(args.steps, 1))
+    for k in kt:
+        kt[k] /= max(args.steps, 1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- roofline of the dominant kernel (algorithmic bytes: SURVEY §8 d / DESIGN.md) ----------------
+    G = sum(((l + 1 + 63) // 64) * 64 for l, o in zip(lens, owned) if o)
+    meas_owned = 0
+    for l in ann.cover_bed.splitlines():
+        f = l.split("\t")
+        if owned[name_to_idx[f[0]]]:
+            meas_owned += sum(int(x) for x in f[10].split(",") if x)
+    alg = {
+        # input stream (13 B/fragment + 4 B CSR offset, 9 B/block) + two 4-byte difference-array targets per block
+        "count_ms": n_frag * 17 + n_blk * 9 + n_blk * 2 * 4,
+        # depth scan: read 4 B + write 4 B per base and strand
+        "scan_ms": G * 2 * 8,
+        # statistics: 4 B per measured intron base and strand (non-directional table reads both strands)
+        "stats_ms": meas_owned * 2 * 4 * (2 if out.get("has_dir") else 1),
+    }
+    dom = max(alg, key=lambda k: kt[k])
+    achieved = alg[dom] / (kt[dom] * 1e-3) / 1e9 if kt[dom] > 0 else 0.0
+    kernels = {k: {"ms": round(kt[k], 4), "alg_bytes": int(alg[k]), "GBps": round(alg[k] / (kt[k] * 1e-3) / 1e9, 1) if kt[k] > 0 else None}
+               for k in alg}
+    kernels["junction_ms"] = {"ms": round(kt["junction_ms"], 4)}
+    roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "reduce_tiles+scan_tiles", "stats_ms": "intron_stats_kernel"}[dom],
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "per_kernel": kernels}
+
+    # ---------------- CPU baseline (oracle, bounded sample, 1 core) ----------------
+    cpu = None
+    extra = {}
+    if world == 1 and args.cpu_pairs > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        # sample = the workload's fragments on the last chromosomes of the header until ~cpu_pairs fragments
+        counts = np.bincount(host.frag_chr, minlength=len(names))
+        keep, tot = [], 0
+        for c in np.argsort(lens):           # smallest chromosomes first
+            if counts[c] == 0:
+                continue
+            keep.append(int(c)); tot += int(counts[c])
+            if tot >= args.cpu_pairs:
+                break
+        sel = np.nonzero(np.isin(host.frag_chr, keep))[0]
+        sample = host.select(sel)
+        refs_s = synth_world.restrict_refs(ann.ref_texts(), [names[c] for c in keep])
+        o = orc.Oracle(refs_s)
+        o.chr_map_update(names, lens)
+        t0 = time.perf_counter()
+        o.process_batch(sample)
+        t1 = time.perf_counter()
+        o.finalize()
+        t2 = time.perf_counter()
+        cres = o.results()
+        cpu = {"value": round(sample.n_frag / (t2 - t0), 1), "unit": "read-pairs/s", "cores": 1, "kind": "port",
+               "sample": "fragments of this workload on %s (%d fragments, reference tables restricted to those chromosomes); "
+                         "count %.2fs + finalize %.2fs; CPU restatement of IRFinder semantics, not the upstream binary" % (
+                             ",".join(names[c] for c in keep), sample.n_frag, t1 - t0, t2 - t1)}
+        # cross-check: the GPU rows of those chromosomes equal the oracle's (same sample => same rows)
+        rows = np.nonzero(np.isin(in_chr, keep))[0]
+        g_depth = out["ir_f64"][1].numpy()[rows]
+        in_chr_s = [i for i, l in enumerate(ann.cover_bed.splitlines()) if name_to_idx[l.split("\t", 1)[0]] in keep]
+        c_depth = cres["nondir"]["intron_depth"]
+        extra["sample_rows_match_oracle"] = bool(len(c_depth) == len(g_depth) and np.array_equal(np.asarray(c_depth), g_depth))
+        o.close()
+
+    # ---------------- host decode bound (reported separately, never part of `value`) ----------------
+    if world == 1 and not args.no_decode_bench:
+        from irfinder_amd.synth.bam import bgzf_compress
+        sim_seq = ReadSimulator(ann, read_len=args.read_len, stranded=bool(args.stranded), seed=seed, with_seq=True)
+        raw = sim_seq.bam(0, 100_000)
+        z = bgzf_compress(raw)
+        rd = engine.Reader()
+        t0 = time.perf_counter()
+        rd.feed(z, bgzf=True)
+        rd.finish()
+        t1 = time.perf_counter()
+        extra["host_decode"] = {"bgzf_MBps_in": round(len(z) / (t1 - t0) / 1e6, 1), "bam_MBps_out": round(len(raw) / (t1 - t0) / 1e6, 1),
+                                "pairs_per_s": round(100_000 / (t1 - t0), 1), "threads": 1,
+                                "note": "zlib inflate + BAM parse + fragment assembly, 2x%dbp records with seq/qual" % args.read_len}
+        extra["pcie_inclusive_pairs_per_s"] = round(args.pairs / (dt / max(args.steps, 1) + h2d_s), 1)
+        extra["h2d"] = {"bytes": int(in_bytes), "seconds": round(h2d_s, 4), "note": "pageable numpy -> device via torch"}
+
+    line = {
+        "metric": "read-pairs/sec to IR table", "value": round(value, 1), "unit": "read-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u64 counters, f64 table columns",
+        "data": "synthetic",
+        "config": {"workload": "%d M simulated 2x%dbp pairs per GPU, %s synthetic GENCODE-like reference (%d introns), %s, %s order%s" % (
+            args.pairs // 1_000_000, args.read_len, {"grch38": "full GRCh38-sized", "chr22": "chr22-only", "toy": "toy"}[args.genome],
+            ann.n_intron, "stranded" if args.stranded else "unstranded", args.order,
+            ", chromosome-sharded over %d GPUs with RCCL collection of the tables" % world if world > 1 else ""),
+            "fragments_per_gpu": n_frag, "blocks_per_gpu": n_blk, "junction_rows": out.get("n_junc"),
+            "parallelism": "chromosome shards x%d" % world},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

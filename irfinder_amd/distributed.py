@@ -1,0 +1,111 @@
+"""Chromosome sharding across the GPUs of one node and the final gather (SURVEY §8 e).
+
+Every counter of the path is a commutative sum over fragments and a fragment touches one chromosome, so the work
+shards by chromosome with NO data-path collective: each rank (one process per GPU) owns a disjoint set of BAM
+references, counts only fragments on them and finalises only introns on them.  The only communication is the
+end-of-run collection of the result tables on rank 0 over torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU node, "gloo" in the CPU tests):
+
+  * fixed-shape tables (IR rows, SpansPoint / ROI / chromosome counters): rows a rank does not own are zero, so the
+    collection is one reduce(SUM) per table (x + 0 = x exactly, also in fp64) — tens of MB, latency-bound;
+  * junction tables have a rank-dependent length: all_gather of the lengths, then a padded gather.
+
+The reference has no counterpart (single process); this is the new [DESIGN] item demanded by north_star.
+"""
+import numpy as np
+
+
+def shard_chromosomes(weights, world):
+    """Longest-processing-time bin packing of chromosomes onto `world` ranks.
+
+    weights: expected work per BAM reference (e.g. fragments, or length as a proxy).  Returns a list of uint8 masks
+    (one per rank, len = n_chr), deterministic so that every rank computes the same assignment."""
+    w = np.asarray(weights, dtype=np.float64)
+    order = np.argsort(-w, kind="stable")
+    load = np.zeros(world)
+    masks = [np.zeros(len(w), np.uint8) for _ in range(world)]
+    for c in order:
+        r = int(np.argmin(load))            # ties -> lowest rank
+        masks[r][c] = 1
+        load[r] += w[c]
+    return masks
+
+
+def plane_bases(chr_lens, owned):
+    """chr_base[] exactly as the engine lays out the depth planes of a rank (owned references only, len+1 rounded
+    up to 64) — needed to decode that rank's packed junction keys."""
+    base = np.zeros(len(chr_lens) + 1, np.uint64)
+    off = 0
+    for i, l in enumerate(chr_lens):
+        base[i] = off
+        if owned[i]:
+            off += ((int(l) + 1 + 63) // 64) * 64
+    base[len(chr_lens)] = off
+    return base
+
+
+JUNC_SPAN_BITS = 28
+JUNC_LEFT_SHIFT = JUNC_SPAN_BITS + 1
+
+
+def decode_junction_keys(keys, chr_lens, owned):
+    """Packed keys of one rank -> (chr, left, right, dir) arrays."""
+    keys = np.asarray(keys, np.uint64)
+    base = plane_bases(chr_lens, owned)
+    gl = keys >> np.uint64(JUNC_LEFT_SHIFT)
+    span = (keys >> np.uint64(1)) & np.uint64((1 << JUNC_SPAN_BITS) - 1)
+    d = (keys & np.uint64(1)).astype(np.uint8)
+    owned_idx = np.nonzero(np.asarray(owned))[0]
+    starts = base[owned_idx]
+    k = np.searchsorted(starts, gl, side="right") - 1
+    chr_id = owned_idx[k].astype(np.uint32) if len(keys) else np.zeros(0, np.uint32)
+    left = (gl - starts[k]).astype(np.uint32) if len(keys) else np.zeros(0, np.uint32)
+    right = (left.astype(np.uint64) + span).astype(np.uint32)
+    return chr_id, left, right, d
+
+
+def gather_tables(tables, dist=None, root=0):
+    """Collect the per-rank result tables on `root`.
+
+    tables: dict of torch tensors on the rank's device —
+        fixed shape, zero where not owned: 'ir_f64' [8,n], 'ir_u32' [6,n] (int32 view), 'sp_cnt', 'roi_cnt', 'chr_cnt'
+        variable length:                   'junc_keys' (int64 view of the packed keys), 'junc_counts' (int32)
+    Returns on root: dict with the summed fixed tables and 'junc_keys'/'junc_counts' as lists (one entry per rank);
+    on other ranks: None.  With dist None (single process) the input is returned in the same shape."""
+    import torch
+    fixed = [k for k in ("ir_f64", "ir_u32", "ir_dir_f64", "ir_dir_u32", "sp_cnt", "roi_cnt", "chr_cnt") if k in tables]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = {k: tables[k] for k in fixed}
+        out["junc_keys"] = [tables["junc_keys"]]
+        out["junc_counts"] = [tables["junc_counts"]]
+        return out
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out = {}
+    for k in fixed:
+        t = tables[k].contiguous()
+        dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+        out[k] = t
+    # junctions: lengths, then padded gather
+    n_local = torch.tensor([tables["junc_keys"].numel()], dtype=torch.int64, device=tables["junc_keys"].device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    for name, dt in (("junc_keys", torch.int64), ("junc_counts", torch.int32)):
+        pad = torch.zeros(m, dtype=dt, device=tables[name].device)
+        pad[: sizes[rank]] = tables[name]
+        if rank == root:
+            bufs = [torch.zeros_like(pad) for _ in range(world)]
+            dist.gather(pad, bufs, dst=root)
+            out[name] = [b[:s] for b, s in zip(bufs, sizes)]
+        else:
+            dist.gather(pad, None, dst=root)
+    return out if rank == root else None
+
+
+def mask_unowned_rows(ir_f64, ir_u32, intron_owned):
+    """Zero the IR rows of introns this rank does not own (in place), so reduce(SUM) acts as a gather."""
+    m = intron_owned.to(ir_f64.device)
+    ir_f64.mul_(m.to(ir_f64.dtype).unsqueeze(0))
+    ir_u32.mul_(m.to(ir_u32.dtype).unsqueeze(0))
+    return ir_f64, ir_u32
