@@ -21,7 +21,11 @@ namespace dev {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kFragsPerThread = 8;
+constexpr int kChunk = kThreads * kFragsPerThread;   // fragments per workgroup iteration
 constexpr int kChrBins = 2048;      // LDS histogram covers refIDs < 1024; larger ones go straight to global
+constexpr uint32_t kWin = 4096;     // positions of the LDS difference-array window (per strand)
 
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t key) {
     // first index in [lo,hi) with a[idx] >= key
@@ -32,72 +36,150 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
     return lo;
 }
 
+// A workgroup walks chunks of kChunk consecutive fragments.  Per chunk:
+//   1. every thread counts the junction events of its fragments; one block-wide scan and ONE global atomic reserve
+//      the chunk's slice of the event buffer (a single shared counter bumped per wave costs >15 ms at 50 M pairs);
+//   2. the fragments are processed; difference events that fall in the chunk's window [win, win + kWin) of the plane
+//      (coordinate-sorted input: nearly all of them) are accumulated in LDS, the rest go to global atomics;
+//   3. the window is flushed: one global atomic per non-zero position instead of one per event.
 __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev B) {
     __shared__ uint32_t s_chr[kChrBins];
+    __shared__ int32_t s_tile[2 * kWin];
+    __shared__ uint32_t s_wsum[kWaves];
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_win;
     for (int k = threadIdx.x; k < kChrBins; k += kThreads) s_chr[k] = 0;
+    for (int k = threadIdx.x; k < (int)(2 * kWin); k += kThreads) s_tile[k] = 0;
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t lane_lt = (1ull << lane) - 1ull;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t err = 0;
-    const uint32_t stride = gridDim.x * kThreads;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < B.n_frag; i += stride) {
-        const uint32_t chr = B.frag_chr[i];
-        if (chr >= T.n_chr) { err |= ERR_CHR_RANGE; continue; }
-        if (!T.chr_owned[chr]) continue;
-        const uint32_t dir = B.frag_flags[i] & 1u;
-        // ---- FragmentsInChr
-        if (chr < kChrBins / 2) atomicAdd(&s_chr[chr * 2 + dir], 1u);
-        else atomicAdd(&T.chr_cnt[chr * 2 + dir], 1u);
-        // ---- FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
-        {
-            const uint32_t r0 = T.roi_off[chr], r1 = T.roi_off[chr + 1];
-            if (r1 > r0) {
-                const uint32_t fs = B.frag_start[i], fe = B.frag_end[i];
-                const uint32_t r = lower_bound_u32(T.roi_end, r0, r1, fe);
-                if (r < r1 && T.roi_start[r] <= fs)
-                    atomicAdd(&T.roi_cnt[(uint64_t)dir * T.n_roi + T.roi_idx[r]], 1u);
-            }
-        }
-        // ---- per aligned block
-        const uint64_t base = T.chr_base[chr];
-        const uint32_t clen = T.chr_len[chr];
-        int32_t* __restrict__ plane = T.diff + (uint64_t)dir * T.plane_stride + base;
-        const uint32_t p0 = T.sp_off[chr], p1 = T.sp_off[chr + 1];
-        uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
-        const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
-        uint32_t prev_end = 0, prev_len = 0, prev_read = 0xffu;
-        for (uint32_t k = k0; k < k1; k++) {
-            const uint32_t bs = B.blk_start[k], bl = B.blk_len[k], rd = B.blk_read[k];
-            uint32_t be = bs + bl;
-            if (be > clen || be < bs) { err |= ERR_BLOCK_RANGE; be = clen; }
-            if (bs < be) {
-                // CoverageBlocks / FragmentsMap: difference events
-                __hip_atomic_fetch_add(plane + bs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(plane + be, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // SpansPoint
-                if (bl > T.sp_min_len && p1 > p0) {
-                    const uint32_t lo = bs + T.sp_lo_add, hi = be - T.sp_hi_sub;
-                    for (uint32_t p = lower_bound_u32(T.sp_pos, p0, p1, lo); p < p1 && T.sp_pos[p] <= hi; p++)
-                        atomicAdd(&sp_cnt[p], 1u);
+    const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t f0 = c * kChunk;
+        // ---- 1. junction events of this thread's fragments; window origin
+        uint32_t my_events = 0;
+        if (!(T.ablate & 8u)) {
+#pragma unroll
+            for (int j = 0; j < kFragsPerThread; j++) {
+                const uint32_t i = f0 + j * kThreads + threadIdx.x;
+                if (i >= B.n_frag) break;
+                const uint32_t chr = B.frag_chr[i];
+                if (chr >= T.n_chr || !T.chr_owned[chr]) continue;
+                const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
+                uint32_t prev_len = 0, prev_read = 0xffu;
+                for (uint32_t k = k0; k < k1; k++) {
+                    const uint32_t bl = B.blk_len[k], rd = B.blk_read[k];
+                    my_events += (rd == prev_read && prev_len >= T.junc_min_flank && bl >= T.junc_min_flank) ? 1u : 0u;
+                    prev_len = bl; prev_read = rd;
                 }
             }
-            // JunctionCount: gap between two consecutive blocks of the same read
-            const bool emit = (rd == prev_read) && prev_len >= T.junc_min_flank && bl >= T.junc_min_flank;
-            const uint64_t mask = __ballot(emit);
-            if (emit) {
-                const uint64_t gleft = base + prev_end;
-                const uint32_t span = bs - prev_end;
-                const int leader = __ffsll((long long)mask) - 1;
-                unsigned long long slot = 0;
-                if ((int)lane == leader) slot = atomicAdd(T.junc_count, (unsigned long long)__popcll(mask));
-                slot = __shfl(slot, leader) + (unsigned long long)__popcll(mask & lane_lt);
-                if (bs < prev_end || span >= (1u << kJuncSpanBits) || gleft >= kJuncMaxGlobal) err |= ERR_JUNC_RANGE;
-                else if (slot >= T.junc_capacity) err |= ERR_JUNC_CAPACITY;
-                else T.junc_keys[slot] = (gleft << kJuncLeftShift) | ((uint64_t)span << 1) | dir;
-            }
-            prev_end = bs + bl; prev_len = bl; prev_read = rd;
         }
+        uint32_t incl = my_events;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += o;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        if (threadIdx.x == 0) {
+            const uint32_t chr = B.frag_chr[f0];
+            unsigned long long w = 0;
+            if (chr < T.n_chr) w = (T.chr_base[chr] + B.frag_start[f0]) & ~63ull;
+            s_win = w;
+        }
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) { const uint32_t v = s_wsum[w]; if (w < (int)wave) before += v; total += v; }
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(T.junc_count, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        unsigned long long slot = s_base + before + incl - my_events;
+        const unsigned long long win = s_win;
+
+        // ---- 2. the fragments
+#pragma unroll 1
+        for (int j = 0; j < kFragsPerThread; j++) {
+            const uint32_t i = f0 + j * kThreads + threadIdx.x;
+            if (i >= B.n_frag) break;
+            const uint32_t chr = B.frag_chr[i];
+            if (chr >= T.n_chr) { err |= ERR_CHR_RANGE; continue; }
+            if (!T.chr_owned[chr]) continue;
+            const uint32_t dir = B.frag_flags[i] & 1u;
+            // FragmentsInChr
+            if (!(T.ablate & 16u)) {
+                if (chr < kChrBins / 2) atomicAdd(&s_chr[chr * 2 + dir], 1u);
+                else atomicAdd(&T.chr_cnt[chr * 2 + dir], 1u);
+            }
+            // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
+            if (!(T.ablate & 4u)) {
+                const uint32_t r0 = T.roi_off[chr], r1 = T.roi_off[chr + 1];
+                if (r1 > r0) {
+                    const uint32_t fs = B.frag_start[i], fe = B.frag_end[i];
+                    const uint32_t r = lower_bound_u32(T.roi_end, r0, r1, fe);
+                    if (r < r1 && T.roi_start[r] <= fs)
+                        atomicAdd(&T.roi_cnt[(uint64_t)dir * T.n_roi + T.roi_idx[r]], 1u);
+                }
+            }
+            // per aligned block
+            const uint64_t base = T.chr_base[chr];
+            const uint32_t clen = T.chr_len[chr];
+            int32_t* __restrict__ plane = T.diff + (uint64_t)dir * T.plane_stride;
+            int32_t* tile = s_tile + dir * kWin;
+            const uint32_t p0 = T.sp_off[chr], p1 = T.sp_off[chr + 1];
+            uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
+            const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
+            uint32_t prev_end = 0, prev_len = 0, prev_read = 0xffu;
+            for (uint32_t k = k0; k < k1; k++) {
+                const uint32_t bs = B.blk_start[k], bl = B.blk_len[k], rd = B.blk_read[k];
+                uint32_t be = bs + bl;
+                if (be > clen || be < bs) { err |= ERR_BLOCK_RANGE; be = clen; }
+                if (bs < be && !(T.ablate & 1u)) {
+                    // CoverageBlocks / FragmentsMap: difference events, LDS window first
+                    const uint64_t gs = base + bs, ge = base + be;
+                    const uint64_t os = gs - win, oe = ge - win;
+                    if (os < kWin) atomicAdd(&tile[os], 1);
+                    else __hip_atomic_fetch_add(plane + gs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (oe < kWin) atomicAdd(&tile[oe], -1);
+                    else __hip_atomic_fetch_add(plane + ge, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (bs < be && !(T.ablate & 2u)) {
+                    // SpansPoint
+                    if (bl > T.sp_min_len && p1 > p0) {
+                        const uint32_t lo = bs + T.sp_lo_add, hi = be - T.sp_hi_sub;
+                        for (uint32_t p = lower_bound_u32(T.sp_pos, p0, p1, lo); p < p1 && T.sp_pos[p] <= hi; p++)
+                            atomicAdd(&sp_cnt[p], 1u);
+                    }
+                }
+                // JunctionCount: gap between two consecutive blocks of the same read
+                if ((rd == prev_read) && prev_len >= T.junc_min_flank && bl >= T.junc_min_flank && !(T.ablate & 8u)) {
+                    const uint64_t gleft = base + prev_end;
+                    const uint32_t span = bs - prev_end;
+                    if (bs < prev_end || span >= (1u << kJuncSpanBits) || gleft >= kJuncMaxGlobal) {
+                        err |= ERR_JUNC_RANGE;
+                        if (slot < T.junc_capacity) T.junc_keys[slot] = 0ull;      // keep the slot defined; the run is rejected
+                    } else if (slot >= T.junc_capacity) {
+                        err |= ERR_JUNC_CAPACITY;
+                    } else {
+                        T.junc_keys[slot] = (gleft << kJuncLeftShift) | ((uint64_t)span << 1) | dir;
+                    }
+                    slot++;
+                }
+                prev_end = bs + bl; prev_len = bl; prev_read = rd;
+            }
+        }
+        __syncthreads();
+        // ---- 3. flush the window
+        for (uint32_t k = threadIdx.x; k < 2 * kWin; k += kThreads) {
+            const int32_t v = s_tile[k];
+            if (v) {
+                const uint32_t d = k >= kWin ? 1u : 0u;
+                __hip_atomic_fetch_add(T.diff + (uint64_t)d * T.plane_stride + win + (k - d * kWin), v, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                s_tile[k] = 0;
+            }
+        }
+        __syncthreads();
     }
     if (err) atomicOr(T.err_flags, err);
     __syncthreads();
@@ -111,8 +193,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;
-    uint32_t blocks = (B.n_frag + kThreads - 1) / kThreads;
-    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    uint32_t blocks = (B.n_frag + kChunk - 1) / kChunk;
+    if (blocks > 256u * 6u) blocks = 256u * 6u;
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, T, B);
 }
 

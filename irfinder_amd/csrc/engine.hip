@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -418,6 +419,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.sp_min_len = P.sp_overhang_left + P.sp_overhang_right;
     T.sp_lo_add = P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u);
     T.sp_hi_sub = P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u);
+    { const char* ab = getenv("IRF_ABLATE"); T.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
     T.plane_stride = plane_stride;
     T.junc_capacity = d_junc_a.cap;
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;

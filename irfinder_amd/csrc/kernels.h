@@ -33,7 +33,7 @@ struct CountTables {
     uint32_t sp_min_len;       // block is considered only if len > sp_min_len (= L + R)
     uint32_t sp_lo_add;        // candidates are the points in [bs + sp_lo_add, be - sp_hi_sub]
     uint32_t sp_hi_sub;
-    uint32_t pad0;
+    uint32_t ablate;           // diagnostic only (IRF_ABLATE env): bit0 depth, 1 SpansPoint, 2 ROI, 3 junction, 4 chr
     uint64_t plane_stride;     // elements per strand plane of the difference array
     uint64_t junc_capacity;
     const uint64_t* chr_base;  // [n_chr]  offset of the chromosome inside a plane
