@@ -7,7 +7,8 @@
 //
 // HBM layout (per context; G = sum over owned BAM references of len+1 rounded
 // up to 64):
-//   diff/depth  int32 [2 strands][G]      difference events, scanned in place
+//   diff        int32 [2 strands][G]      difference events (+1 block start, -1 block end)
+//   carry       uint32 [2][G/256]         depth just before each 256-position segment
 //   junc_keys   uint64 [capacity] x2      packed junction events + sort buffer
 //   sp_pos/cnt, roi_*, chr_*              reference tables and their counters
 //   intron tables                         global coordinates of measured blocks
@@ -87,6 +88,7 @@ struct irf_ctx {
 
     // ---- device state ----
     DevBuf<int32_t> d_diff;
+    DevBuf<uint32_t> d_carry;                    // [2][plane_stride/256] depth before each segment (after finalize)
     DevBuf<uint64_t> d_chr_base;
     DevBuf<uint32_t> d_chr_len;
     DevBuf<uint8_t> d_chr_owned;
@@ -242,7 +244,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         chr_base[i] = off;
         if (chr_owned[i]) off += (((uint64_t)chr_len[i] + 1 + 63) / 64) * 64;
     }
-    plane_stride = off;
+    plane_stride = ((off + dev::kScanTile - 1) / dev::kScanTile) * dev::kScanTile;     // whole scan tiles / depth segments
     if (plane_stride >= dev::kJuncMaxGlobal) return fail(IRF_E_RANGE, "genome too large for the packed junction key (>= 2^34 bases)");
     TRY(upload(this, d_chr_base, chr_base));
     TRY(upload(this, d_chr_len, chr_len));
@@ -253,8 +255,10 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     }
     TRY(alloc_zero(this, d_chr_cnt, (size_t)n * 2));
     {
-        hipError_t e = d_ws.reserve(dev::scan_workspace_elems(2 * plane_stride));
-        if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the scan workspace failed");
+        const uint64_t n_seg = 2 * plane_stride / dev::kDepthSegment;
+        hipError_t e = d_carry.reserve(n_seg);
+        if (e == hipSuccess) e = d_ws.reserve(dev::scan_workspace_elems(n_seg));
+        if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth carries / scan workspace failed");
     }
 
     // ---- ROI: (slot,end)-sorted, BAM chromosomes only ----
@@ -554,7 +558,7 @@ int irf_ctx::finalize() {
     d_sorted = d_junc_a.p;
     if (n_events) {
         if (d_junc_b.reserve(d_junc_a.cap) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort buffer failed");
-        uint64_t ws_need = std::max(dev::radix_workspace_elems(n_events), dev::scan_workspace_elems(std::max<uint64_t>(n_events, 2 * plane_stride)));
+        uint64_t ws_need = std::max(dev::radix_workspace_elems(n_events), dev::scan_workspace_elems(std::max<uint64_t>(n_events, 2 * plane_stride / dev::kDepthSegment)));
         if (ws_need > d_ws.cap) { if (d_ws.reserve(ws_need) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort workspace failed"); }
         unsigned long long init[2] = {0ull, ~0ull};
         HIP_TRY(hipMemcpyAsync(d_scalars.p + 1, init, sizeof init, hipMemcpyHostToDevice, stream));
@@ -602,8 +606,9 @@ int irf_ctx::finalize() {
     unsigned long long votes[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(votes, d_scalars.p + 3, sizeof votes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(ev[1], stream));
-    // ---- depth: prefix scan of the difference planes, in place ----
-    dev::launch_inclusive_scan_i32(d_diff.p, 2 * plane_stride, d_ws.p, stream);
+    // ---- depth: one read of the difference planes -> per-segment sums -> carries (exclusive scan, in place) ----
+    dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_carry.p, stream);
+    dev::launch_exclusive_scan_u32(d_carry.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[2], stream));
     HIP_TRY(hipStreamSynchronize(stream));
     // JunctionCount::Directional() (OQ-5)
@@ -615,7 +620,7 @@ int irf_ctx::finalize() {
         if (t == 1 && directionality == 0) break;
         dev::IntronTables T;
         memset(&T, 0, sizeof T);
-        T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.depth = d_diff.p;
+        T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
         T.valid = d_in_valid.p; T.strand_plus = d_in_plus.p; T.g_start = d_in_gstart.p; T.g_end = d_in_gend.p;
         T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
         T.sp_idx_start = d_sp_idx_s.p; T.sp_idx_end = d_sp_idx_e.p; T.sp_cnt = d_sp_cnt.p;
@@ -895,15 +900,22 @@ int irf_get_depth(irf_ctx* c, uint32_t chr, uint32_t start, uint32_t end, uint32
     if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
     size_t n = end - start;
     if (!n) return 0;
-    std::vector<uint32_t> a(n), b;
-    int p0 = dir == 2 ? 0 : (int)dir;
-    if (hipMemcpy(a.data(), c->d_diff.p + (uint64_t)p0 * c->plane_stride + c->chr_base[chr] + start, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
-        return c->fail(IRF_E_DEVICE, "hipMemcpy depth");
-    if (dir == 2) {
-        b.resize(n);
-        if (hipMemcpy(b.data(), c->d_diff.p + c->plane_stride + c->chr_base[chr] + start, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    // depth = carry of the enclosing 256-position segment + running sum of the difference events (host side)
+    std::vector<uint32_t> a(n, 0u);
+    for (int p = 0; p < 2; p++) {
+        if (dir != 2 && (int)dir != p) continue;
+        const uint64_t g0 = c->chr_base[chr] + start, g1 = c->chr_base[chr] + end;
+        const uint64_t seg = g0 / irf::dev::kDepthSegment, e0 = seg * irf::dev::kDepthSegment;
+        std::vector<int32_t> ev(g1 - e0);
+        uint32_t carry = 0;
+        if (hipMemcpy(ev.data(), c->d_diff.p + (uint64_t)p * c->plane_stride + e0, ev.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&carry, c->d_carry.p + (uint64_t)p * (c->plane_stride / irf::dev::kDepthSegment) + seg, 4, hipMemcpyDeviceToHost) != hipSuccess)
             return c->fail(IRF_E_DEVICE, "hipMemcpy depth");
-        for (size_t i = 0; i < n; i++) a[i] += b[i];
+        uint32_t run = carry;
+        for (uint64_t x = e0; x < g1; x++) {
+            run += (uint32_t)ev[x - e0];
+            if (x >= g0) a[x - g0] += run;
+        }
     }
     memcpy(out, a.data(), n * 4);
     return 0;

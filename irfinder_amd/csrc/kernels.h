@@ -72,8 +72,10 @@ void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s);
 constexpr uint32_t kScanTile = 4096;
 // number of uint32 workspace elements a scan over n elements needs
 uint64_t scan_workspace_elems(uint64_t n);
-// in-place inclusive prefix sum of int32 (wrap-around arithmetic)
-void launch_inclusive_scan_i32(int32_t* data, uint64_t n, uint32_t* workspace, hipStream_t s);
+// Depth carries: sums of each kDepthSegment-element segment of the difference planes (then scanned exclusively in
+// place with launch_exclusive_scan_u32): carry[k] = depth just before position k * kDepthSegment.  n % 4096 == 0.
+constexpr uint32_t kDepthSegment = 256;
+void launch_segment_sums(const int32_t* diff, uint64_t n, uint32_t* seg_sums, hipStream_t s);
 // exclusive prefix sum, out may alias in
 void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* workspace, hipStream_t s);
 
@@ -113,7 +115,8 @@ struct IntronTables {
     uint32_t n_intron;
     uint32_t n_sp;
     uint64_t plane_stride;
-    const int32_t* depth;          // [2][plane_stride] (scanned)
+    const int32_t* diff;           // [2][plane_stride] difference events (NOT scanned)
+    const uint32_t* carry;         // [2][plane_stride/256] depth just before each 256-position segment
     const uint8_t* valid;          // [n_intron] chromosome present in the BAM header and owned
     const uint8_t* strand_plus;    // [n_intron] 1 unless strand == '-'
     const uint64_t* g_start;       // global start / end of the intron

@@ -1,15 +1,18 @@
 // scan.hip — device-wide prefix sums (gfx950).
 //
 // The per-strand difference arrays written by count.hip become per-base depth
-// through one inclusive prefix sum over the whole plane pair: every aligned
+// through a prefix sum over the whole plane pair: every aligned
 // block contributes +1 and -1 inside its own chromosome, so each chromosome's
 // events sum to zero and the flat scan over the concatenated planes equals the
 // segmented (per-chromosome, per-strand) scan.  This is what turns upstream's
 // CoverageBlock::RecordCover event lists (⟨upstream⟩ CoverageBlock.cpp) into
-// depth.  Reduce-then-scan in tiles of 4096 elements, HBM-bound:
-//   reduce pass reads 4 B/element, scan pass reads 4 B and writes 4 B.
-// The same kernels give the exclusive scans the radix sort and the junction
-// compaction need.
+// depth.  The planes are read ONCE here (segment_sums_kernel: 4 B per base, one
+// sum per 256 bases), the 256x smaller array of segment sums is scanned, and
+// the statistics kernel (stats.hip) rebuilds depth inside each segment on the
+// fly — the scanned planes are never written back (that would cost another
+// 4 B read + 4 B write per base).  The generic reduce-then-scan below (tiles of
+// 4096) scans the segment sums and serves the radix sort and the junction
+// compaction.
 #include "kernels.h"
 
 namespace irf {
@@ -118,6 +121,21 @@ __global__ __launch_bounds__(kThreads) void scan_tiles_kernel(const uint32_t* in
     }
 }
 
+// One 256-position segment per (row, wave): the 64 lanes of a wave load 64 x uint4 = 1 KiB contiguous.
+// seg_sums[tile * 16 + row * 4 + wave] = sum of that segment.  Reads 4 B per base, writes 4 B per 256 bases.
+__global__ __launch_bounds__(kThreads) void segment_sums_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ seg_sums) {
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
+    const uint4* p = reinterpret_cast<const uint4*>(in + tile0);
+    uint4 v[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; r++) v[r] = p[r * kThreads + threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+        const uint32_t s = wave_sum(v[r].x + v[r].y + v[r].z + v[r].w);
+        if ((threadIdx.x & 63) == 0) seg_sums[(uint64_t)blockIdx.x * (kScanTile / 256) + r * (kThreads / 64) + (threadIdx.x >> 6)] = s;
+    }
+}
+
 inline uint64_t tiles_of(uint64_t n) { return (n + kScanTile - 1) / kScanTile; }
 
 // exclusive scan of `in` (n elements) into `out`, using ws for the tile partials of every level
@@ -145,17 +163,10 @@ uint64_t scan_workspace_elems(uint64_t n) {
     return total + 16;
 }
 
-void launch_inclusive_scan_i32(int32_t* data, uint64_t n, uint32_t* ws, hipStream_t s) {
+void launch_segment_sums(const int32_t* diff, uint64_t n, uint32_t* seg_sums, hipStream_t s) {
     if (n == 0) return;
-    uint32_t* d = reinterpret_cast<uint32_t*>(data);
-    const uint64_t nt = tiles_of(n);
-    if (nt <= 1) {
-        hipLaunchKernelGGL(scan_tiles_kernel<true>, dim3(1), dim3(kThreads), 0, s, (const uint32_t*)d, d, n, (const uint32_t*)nullptr);
-        return;
-    }
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((uint32_t)nt), dim3(kThreads), 0, s, (const uint32_t*)d, n, ws);
-    exclusive_scan_rec(ws, ws, nt, ws + nt, s);
-    hipLaunchKernelGGL(scan_tiles_kernel<true>, dim3((uint32_t)nt), dim3(kThreads), 0, s, (const uint32_t*)d, d, n, (const uint32_t*)ws);
+    hipLaunchKernelGGL(segment_sums_kernel, dim3((uint32_t)(n / kScanTile)), dim3(kThreads), 0, s,
+                       reinterpret_cast<const uint32_t*>(diff), seg_sums);
 }
 
 void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* ws, hipStream_t s) {

@@ -14,7 +14,12 @@
 // The integers that come out are identical to what the map walk yields; the
 // few fp64 operations (divisions, one interpolation) are done in the same order
 // as the CPU restatement, with contraction off, so doubles match bit for bit.
-// HBM-bound: 4 B (one strand) or 8 B (both) per measured base.
+// Depth is never materialised: the workgroup rebuilds it on the fly from the
+// difference planes.  finalize() leaves, for every 256-position segment of a
+// plane, the depth just before the segment ("carry", scan.hip); a wave loads a
+// segment as 64 x int4, one wave-wide prefix sum gives the 256 depths.  Both
+// strands (non-directional table) are summed BEFORE the prefix (it is linear).
+// HBM-bound: 4 B (one strand) or 8 B (both) per measured base, read once.
 #include "kernels.h"
 
 namespace irf {
@@ -30,19 +35,59 @@ constexpr int kBinsPerThread = kBins / kThreads;   // 8
 constexpr int kMaxFlank = 1024;
 constexpr int kQueries = 8;
 
-struct Query { unsigned long long rank; uint32_t value; unsigned long long sum_below; };
+constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 
 struct Ctx {
-    const int32_t* d0;
+    const int32_t* d0;              // difference planes
     const int32_t* d1;
-    int plane;          // 0,1: one strand; 2: both
+    const uint32_t* c0;             // carries, one per 256-position segment
+    const uint32_t* c1;
+    int plane;                      // 0,1: one strand; 2: both
     bool valid;
-    __device__ __forceinline__ uint32_t val(uint64_t g) const {
-        if (!valid) return 0u;
-        if (plane == 2) return (uint32_t)d0[g] + (uint32_t)d1[g];
-        return (uint32_t)(plane ? d1[g] : d0[g]);
-    }
 };
+
+// Calls f(x, depth[x]) for every global position x in [gs, ge), spread over the whole workgroup.
+// Every wave walks whole segments, so the shuffles inside always run with 64 active lanes.
+template <class F>
+__device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
+    if (gs >= ge) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (!C.valid) {                 // chromosome absent from the BAM header / not owned: depth 0 everywhere
+        for (uint64_t x = gs + threadIdx.x; x < ge; x += kThreads) f(x, 0u);
+        return;
+    }
+    const uint64_t k0 = gs / kSeg, k1 = (ge - 1) / kSeg;
+    for (uint64_t k = k0 + wave; k <= k1; k += kWaves) {
+        const uint64_t e0 = k * kSeg + lane * 4u;
+        int4 a;
+        uint32_t carry;
+        if (C.plane == 2) {
+            const int4 u = *reinterpret_cast<const int4*>(C.d0 + e0);
+            const int4 v = *reinterpret_cast<const int4*>(C.d1 + e0);
+            a.x = u.x + v.x; a.y = u.y + v.y; a.z = u.z + v.z; a.w = u.w + v.w;
+            carry = C.c0[k] + C.c1[k];
+        } else if (C.plane == 1) {
+            a = *reinterpret_cast<const int4*>(C.d1 + e0);
+            carry = C.c1[k];
+        } else {
+            a = *reinterpret_cast<const int4*>(C.d0 + e0);
+            carry = C.c0[k];
+        }
+        const uint32_t t = (uint32_t)(a.x + a.y + a.z + a.w);
+        uint32_t incl = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += o;
+        }
+        const uint32_t v0 = carry + incl - t + (uint32_t)a.x;
+        const uint32_t v1 = v0 + (uint32_t)a.y, v2 = v1 + (uint32_t)a.z, v3 = v2 + (uint32_t)a.w;
+        if (e0 + 0 >= gs && e0 + 0 < ge) f(e0 + 0, v0);
+        if (e0 + 1 >= gs && e0 + 1 < ge) f(e0 + 1, v1);
+        if (e0 + 2 >= gs && e0 + 2 < ge) f(e0 + 2, v2);
+        if (e0 + 3 >= gs && e0 + 3 < ge) f(e0 + 3, v3);
+    }
+}
 
 // Exclusive prefix over the 256 threads of (count, sum); s_w* are LDS scratch of kWaves entries.
 __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long tsum, uint32_t& pre,
@@ -118,8 +163,10 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     const uint32_t i = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     Ctx C;
-    C.d0 = T.depth;
-    C.d1 = T.depth + T.plane_stride;
+    C.d0 = T.diff;
+    C.d1 = T.diff + T.plane_stride;
+    C.c0 = T.carry;
+    C.c1 = T.carry + T.plane_stride / kSeg;
     C.valid = T.valid[i] != 0;
     C.plane = 2;
     if (T.directionality != 0) C.plane = ((T.strand_plus[i] != 0) == (T.directionality > 0)) ? 1 : 0;
@@ -148,13 +195,14 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                         const uint64_t bs = T.blk_gstart[b], be = bs + T.blk_len[b];
                         const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
                         if (s < e) {
-                            for (uint64_t x = s + tid; x < e; x += kThreads) s_win[n + (uint32_t)(x - s)] = C.val(x);
+                            const uint32_t at = n;
+                            for_each_depth(C, s, e, [&](uint64_t x, uint32_t v) { s_win[at + (uint32_t)(x - s)] = v; });
                             n += (uint32_t)(e - s);
                         }
                     }
                 } else {
                     const uint64_t s = w0[wi], e = w1[wi];
-                    for (uint64_t x = s + tid; x < e; x += kThreads) s_win[(uint32_t)(x - s)] = C.val(x);
+                    for_each_depth(C, s, e, [&](uint64_t x, uint32_t v) { s_win[(uint32_t)(x - s)] = v; });
                     n = (uint32_t)(e - s);
                 }
             }
@@ -174,14 +222,12 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         bool ovf = false;
         for (uint32_t b = b0; b < b1; b++) {
             const uint64_t bs = T.blk_gstart[b];
-            const uint32_t bl = T.blk_len[b];
-            for (uint32_t x = tid; x < bl; x += kThreads) {
-                const uint32_t v = C.val(bs + x);
+            for_each_depth(C, bs, bs + T.blk_len[b], [&](uint64_t, uint32_t v) {
                 if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
                 vmax = v > vmax ? v : vmax;
                 tsum += v;
                 nz += v ? 1u : 0u;
-            }
+            });
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
@@ -274,16 +320,14 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                 __syncthreads();
                 for (uint32_t b = b0; b < b1; b++) {
                     const uint64_t bs = T.blk_gstart[b];
-                    const uint32_t bl = T.blk_len[b];
-                    for (uint32_t x = tid; x < bl; x += kThreads) {
-                        const uint32_t v = C.val(bs + x);
+                    for_each_depth(C, bs, bs + T.blk_len[b], [&](uint64_t, uint32_t v) {
                         const bool in = lv == 0 || (shift + kBinBits >= 32 ? true : (v >> (shift + kBinBits)) == prefix);
                         if (in) {
                             const uint32_t bin = (v >> shift) & (uint32_t)(kBins - 1);
                             atomicAdd(&s_cnt[bin], 1u);
                             atomicAdd(&s_sum[bin], (unsigned long long)v);
                         }
-                    }
+                    });
                 }
                 __syncthreads();
                 uint32_t c[kBinsPerThread];
