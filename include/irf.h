@@ -258,6 +258,11 @@ typedef struct irf_timing {
 } irf_timing;
 int irf_get_timing(irf_ctx* ctx, irf_timing* out);
 
+/* Page-locked host memory for batch arrays (async H2D copies need it).  No
+ * upstream counterpart: upstream never leaves the host.                     */
+int irf_host_alloc(size_t bytes, void** out);
+void irf_host_free(void* p);
+
 /* ------------------------------------------------------------------------ */
 /* Host reader.  Replaces BAM2blocks (⟨upstream⟩ BAM2blocks.cpp:
  * readBamHeader, processAll, processPair, processSingle, cigar2block) for

@@ -947,6 +947,12 @@ int irf_export_device(irf_ctx* c, uint32_t what, void* dst, uint64_t* n_out) {
     return 0;
 }
 
+int irf_host_alloc(size_t bytes, void** out) {
+    if (!out) return IRF_E_ARG;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : IRF_E_NOMEM;
+}
+void irf_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int irf_get_timing(irf_ctx* c, irf_timing* out) {
     if (!c || !out) return IRF_E_ARG;
     *out = c->timing;

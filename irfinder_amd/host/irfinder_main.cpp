@@ -1,0 +1,135 @@
+// irfinder_main.cpp — command-line drop-in for the upstream engine binary.
+//
+//   irfinder_hip OUTDIR ref-cover.bed ref-sj.ref ref-read-continues.ref ref-ROI.bed [--bgzf] [--device N]
+//                [--via-adapter] < input.bam
+//
+// Same positional argv as ⟨upstream⟩ irfinder.cpp main(): reads the
+// BAM stream from stdin (raw, as `gzip -cd x.bam` yields it, or BGZF with
+// --bgzf), writes the IRFinder-*.txt files into OUTDIR and the reader summary
+// to stdout.  --via-adapter routes every fragment through the
+// ReadBlockProcessor-shaped adapter (hip_block_processor.h) instead of handing
+// the reader's SoA batches to the engine directly; both give identical files.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/irf.h"
+#include "hip_block_processor.h"
+
+static int die(const char* what, const char* msg) {
+    fprintf(stderr, "irfinder_hip: %s: %s\n", what, msg);
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    std::vector<const char*> pos;
+    bool bgzf = false, via_adapter = false;
+    int device = 0;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--bgzf")) bgzf = true;
+        else if (!strcmp(argv[i], "--via-adapter")) via_adapter = true;
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else pos.push_back(argv[i]);
+    }
+    if (pos.size() < 5) {
+        fprintf(stderr, "usage: %s OUTDIR ref-cover.bed ref-sj.ref ref-read-continues.ref ref-ROI.bed [--bgzf] [--device N] < bam\n", argv[0]);
+        return 2;
+    }
+    irf_params P;
+    irf_params_default(&P);
+    irf_reader* rd = nullptr;
+    if (irf_reader_create(&P, &rd) != 0) return die("reader", "cannot create");
+
+    const size_t kChunk = 8u << 20, kBatchFrags = 1u << 20;
+    std::vector<uint8_t> buf(kChunk);
+    irf_ctx* ctx = nullptr;
+    HipReadBlockProcessor* adapter = nullptr;
+    bool mapped = false;
+    try {
+        if (via_adapter) {
+            adapter = new HipReadBlockProcessor(pos[1], pos[2], pos[3], pos[4], device, &P, (uint32_t)kBatchFrags);
+            ctx = adapter->context();
+        } else {
+            char err[256] = {0};
+            irf_ref* ref = nullptr;
+            if (irf_ref_load_files(pos[1], pos[2], pos[3], pos[4], &ref, err, sizeof err) != 0) return die("reference tables", err);
+            int rc = irf_create(&P, ref, device, &ctx);
+            irf_ref_free(ref);
+            if (rc != 0) return die("irf_create", "no HIP device or bad parameters");
+        }
+        auto drain = [&](bool all) -> int {
+            if (!mapped) {
+                const char* const* names = nullptr;
+                const uint32_t* lens = nullptr;
+                int n = irf_reader_header(rd, &names, &lens);
+                if (n < 0) return 0;
+                if (adapter) {
+                    std::vector<std::string> nm;
+                    for (int i = 0; i < n; i++) nm.emplace_back(names[i]);
+                    adapter->setChrLens(std::vector<uint32_t>(lens, lens + n));
+                    adapter->ChrMapUpdate(nm);
+                } else if (irf_chr_map_update(ctx, (uint32_t)n, names, lens, nullptr) != 0) {
+                    return die("irf_chr_map_update", irf_last_error(ctx));
+                }
+                mapped = true;
+            }
+            irf_batch b;
+            irf_reader_batch(rd, &b);
+            if (b.n_frag == 0 || (!all && b.n_frag < kBatchFrags)) return 0;
+            if (adapter) {
+                FragmentBlocks f;
+                for (uint32_t i = 0; i < b.n_frag; i++) {
+                    f.chr_id = (int)b.frag_chr[i];
+                    f.direction = (b.frag_flags[i] & IRF_FRAG_DIR) != 0;
+                    f.readCount = (b.frag_flags[i] & IRF_FRAG_TWO) ? 2 : 1;
+                    for (int r = 0; r < 2; r++) { f.rStarts[r].clear(); f.rLens[r].clear(); f.readStart[r] = f.readEnd[r] = 0; }
+                    f.readStart[0] = b.frag_start[i];
+                    bool seen1 = false;
+                    for (uint32_t k = b.frag_blk_off[i]; k < b.frag_blk_off[i + 1]; k++) {
+                        int r = b.blk_read[k] ? 1 : 0;
+                        if (r == 1 && !seen1) { f.readStart[1] = b.blk_start[k]; seen1 = true; }
+                        f.rStarts[r].push_back((int)(b.blk_start[k] - f.readStart[r]));
+                        f.rLens[r].push_back((int)b.blk_len[k]);
+                        f.readEnd[r] = b.blk_start[k] + b.blk_len[k];
+                    }
+                    if (f.readCount == 2) f.readEnd[1] = b.frag_end[i]; else f.readEnd[0] = b.frag_end[i];
+                    adapter->ProcessBlocks(f);
+                }
+            } else {
+                uint64_t id = 0;
+                if (irf_submit_batch(ctx, &b, &id) != 0 || irf_wait(ctx, id) != 0) return die("irf_submit_batch", irf_last_error(ctx));
+            }
+            irf_reader_clear_batch(rd);
+            return 0;
+        };
+        size_t n;
+        while ((n = fread(buf.data(), 1, buf.size(), stdin)) > 0) {
+            if (irf_reader_feed(rd, buf.data(), n, bgzf ? 1 : 0) != 0) return die("BAM", irf_reader_last_error(rd));
+            if (int rc = drain(false)) return rc;
+        }
+        if (irf_reader_finish(rd) != 0) return die("BAM", irf_reader_last_error(rd));
+        if (int rc = drain(true)) return rc;
+        if (!mapped) return die("BAM", "no header");
+        if (adapter) {
+            adapter->finish();
+            adapter->writeOutputs(pos[0]);
+        } else {
+            if (irf_finalize(ctx) != 0) return die("irf_finalize", irf_last_error(ctx));
+            if (irf_write_outputs(ctx, pos[0]) != 0) return die("irf_write_outputs", irf_last_error(ctx));
+        }
+    } catch (const std::exception& e) {
+        return die("error", e.what());
+    }
+    irf_reader_stats st;
+    irf_reader_get_stats(rd, &st);
+    printf("Total reads processed\t%llu\nTotal nucleotides\t%llu\nTotal singles processed\t%llu\nTotal pairs processed\t%llu\n"
+           "Short pairs\t%llu\nIntersect pairs\t%llu\nLong pairs\t%llu\nSkipped reads\t%llu\nError reads\t%llu\n",
+           (unsigned long long)st.n_records, (unsigned long long)st.n_nucleotides, (unsigned long long)st.n_singles,
+           (unsigned long long)st.n_pairs, (unsigned long long)st.n_pairs_short, (unsigned long long)st.n_pairs_intersect,
+           (unsigned long long)st.n_pairs_long, (unsigned long long)st.n_skipped, (unsigned long long)st.n_error);
+    irf_reader_destroy(rd);
+    if (adapter) delete adapter; else irf_destroy(ctx);
+    return 0;
+}

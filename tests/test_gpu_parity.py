@@ -217,3 +217,37 @@ def test_device_resident_batch():
     e.finalize()
     o, c = run_orc(ann.ref_texts(), names, lens, [batch])
     assert_results_equal(e.results(), c, rel=0.0, what="device batch")
+
+
+def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
+    """The command-line engine (same argv as upstream's `irfinder`) vs the oracle CLI: every output file byte-identical,
+    through the direct SoA path, through the ReadBlockProcessor adapter (hip_block_processor.h), raw and BGZF input."""
+    import subprocess
+    from irfinder_amd.synth.bam import bgzf_compress
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ann, sim = small_world(seed=31, stranded=True)
+    bam = sim.bam(0, 30000)
+    names = ["ref-cover.bed", "ref-sj.ref", "ref-read-continues.ref", "ref-ROI.bed"]
+    for n, t in zip(names, ann.ref_texts()):
+        (tmp_path / n).write_text(t)
+    (tmp_path / "in.bam.raw").write_bytes(bam)
+    (tmp_path / "in.bam").write_bytes(bgzf_compress(bam))
+    refs = [str(tmp_path / n) for n in names]
+    cpu = tmp_path / "cpu"
+    cpu.mkdir()
+    with open(tmp_path / "in.bam.raw", "rb") as fh:
+        p = subprocess.run([os.path.join(root, "oracle", "irfinder_oracle"), str(cpu)] + refs, stdin=fh, capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    cpu_stdout = p.stdout
+    exe = os.path.join(root, "irfinder_amd", "irfinder_hip")
+    for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam")):
+        out = tmp_path / tag
+        out.mkdir()
+        with open(tmp_path / src, "rb") as fh:
+            p = subprocess.run([exe, str(out)] + refs + extra, stdin=fh, capture_output=True, timeout=120)
+        assert p.returncode == 0, (tag, p.stderr)
+        assert p.stdout == cpu_stdout, tag                       # reader summary
+        files = sorted(os.listdir(cpu))
+        assert files == sorted(os.listdir(out)) and len(files) == 6, tag
+        for f in files:
+            assert filecmp.cmp(out / f, cpu / f, shallow=False), (tag, f)
