@@ -63,7 +63,7 @@ def main():
     from irfinder_amd import distributed as irfdist
     from irfinder_amd import engine
     from irfinder_amd._abi import (COL_IR_NONDIR_F64, COL_IR_NONDIR_U32, COL_IR_DIR_F64, COL_IR_DIR_U32, COL_JUNC_KEYS,
-                                   COL_JUNC_COUNTS, COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, Batch)
+                                   COL_JUNC_COUNTS, COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, COL_KNOWN_CNT, Batch)
     from irfinder_amd.synth import world as synth_world
     from irfinder_amd.synth.annotation import GRCH38, make_annotation, small_chroms
     from irfinder_amd.synth.reads import ReadSimulator
@@ -139,12 +139,16 @@ def main():
         eng.reset()
         eng.submit(dbatch)
         eng.finalize()
+        if world > 1:       # the strandedness vote is global: one all-reduce of two integers
+            v = torch.tensor(eng.votes(), dtype=torch.int64, device=dev)
+            eng.finalize_directional(irfdist.global_directionality(v, dist, eng.params.dir_ratio))
         tabs = {
             "ir_f64": export(COL_IR_NONDIR_F64, (8, n_in), torch.float64),
             "ir_u32": export(COL_IR_NONDIR_U32, (6, n_in), torch.int32),
             "sp_cnt": export(COL_SP_CNT, None, torch.int32),
             "roi_cnt": export(COL_ROI_CNT, None, torch.int32),
             "chr_cnt": export(COL_CHR_CNT, None, torch.int32),
+            "known_cnt": export(COL_KNOWN_CNT, None, torch.int32),
             "junc_keys": export(COL_JUNC_KEYS, None, torch.int64),
             "junc_counts": export(COL_JUNC_COUNTS, None, torch.int32),
         }
@@ -162,6 +166,7 @@ def main():
             out["ir_f64"] = got["ir_f64"].cpu()
             out["ir_u32"] = got["ir_u32"].cpu()
             out["n_junc"] = sum(int(k.numel()) for k in got["junc_keys"])
+            out["known_reads"] = int(got["known_cnt"].sum().item())
 
     def barrier():
         if world > 1:
@@ -282,7 +287,7 @@ def main():
             args.pairs // 1_000_000, args.read_len, {"grch38": "full GRCh38-sized", "chr22": "chr22-only", "toy": "toy"}[args.genome],
             ann.n_intron, "stranded" if args.stranded else "unstranded", args.order,
             ", chromosome-sharded over %d GPUs with RCCL collection of the tables" % world if world > 1 else ""),
-            "fragments_per_gpu": n_frag, "blocks_per_gpu": n_blk, "junction_rows": out.get("n_junc"),
+            "fragments_per_gpu": n_frag, "blocks_per_gpu": n_blk, "novel_junction_rows": out.get("n_junc"), "reads_on_known_junctions": out.get("known_reads"),
             "parallelism": "chromosome shards x%d" % world},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -205,6 +205,12 @@ int irf_wait(irf_ctx* ctx, uint64_t batch_id);
  * irf_get_results.  Replaces the end-of-run half of ⟨upstream⟩ irfinder.cpp
  * main() up to (not including) the file writers.                             */
 int irf_finalize(irf_ctx* ctx);
+/* Multi-GPU (no upstream counterpart; upstream is one process): JunctionCount::Directional() is a vote over ALL
+ * known junctions, so with chromosome shards the votes {same, opposite} of every rank are summed by the host
+ * (one all-reduce of two integers), the decision (same > ratio*opp => +1, opp > ratio*same => -1, else 0) is taken
+ * once and imposed on every rank; the directional table is recomputed where the local decision differed.        */
+int irf_get_votes(irf_ctx* ctx, uint64_t votes[2]);
+int irf_finalize_directional(irf_ctx* ctx, int32_t directionality);
 /* Host view of the results (pointers owned by ctx, valid until reset/destroy). */
 int irf_get_results(irf_ctx* ctx, irf_results* out);
 /* Chromosome slot -> name.  Slots 0..n_chr-1 are the BAM references, further
@@ -236,11 +242,12 @@ typedef enum irf_column {
     IRF_COL_IR_NONDIR_U32 = 1,   /* [6][n_intron] uint32 (5 counts + warning)      */
     IRF_COL_IR_DIR_F64 = 2,
     IRF_COL_IR_DIR_U32 = 3,
-    IRF_COL_JUNC_KEYS = 4,       /* n_obs uint64 packed junction keys, sorted      */
-    IRF_COL_JUNC_COUNTS = 5,     /* n_obs uint32                                   */
+    IRF_COL_JUNC_KEYS = 4,       /* NOVEL junctions: uint64 packed keys, sorted    */
+    IRF_COL_JUNC_COUNTS = 5,     /* ... and their uint32 counts                    */
     IRF_COL_SP_CNT = 6,          /* [2][n_sp] uint32                               */
     IRF_COL_ROI_CNT = 7,         /* [2][n_roi] uint32                              */
-    IRF_COL_CHR_CNT = 8          /* [n_chr][2] uint32                              */
+    IRF_COL_CHR_CNT = 8,         /* [n_chr][2] uint32                              */
+    IRF_COL_KNOWN_CNT = 9        /* [2][n_ref_junction] uint32, ref-sj rows sorted by (slot,left,right) */
 } irf_column;
 int irf_export_device(irf_ctx* ctx, uint32_t what, void* dst_device, uint64_t* n);
 

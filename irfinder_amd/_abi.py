@@ -19,7 +19,7 @@ STATUS = {0: "IRF_OK", -1: "IRF_E_ARG", -2: "IRF_E_PARSE", -3: "IRF_E_RANGE", -4
           -5: "IRF_E_DEVICE", -6: "IRF_E_NOMEM", -7: "IRF_E_IO"}
 
 (COL_IR_NONDIR_F64, COL_IR_NONDIR_U32, COL_IR_DIR_F64, COL_IR_DIR_U32, COL_JUNC_KEYS, COL_JUNC_COUNTS,
- COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT) = range(9)
+ COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, COL_KNOWN_CNT) = range(10)
 
 
 class IrfParams(C.Structure):

@@ -8,9 +8,11 @@
 //   * FragmentsInROI : binary search over the (chr,end)-sorted ROI table
 //   * CoverageBlocks : +1 / -1 into the per-strand difference array (depth comes
 //                      from the prefix scan at finalize)
-//   * SpansPoint     : binary search over the sorted boundary points
-//   * JunctionCount  : packed (chr,left,span,strand) events appended to a buffer
-//                      (wave-aggregated reservation), sort-reduced at finalize
+//   * SpansPoint     : bucket index over the plane + short walk of the sorted points
+//   * JunctionCount  : events on a known junction (ref-sj.ref) bump that junction's
+//                      counter (bucket index + walk; LDS-cached per chunk); novel junctions
+//                      are appended as packed (chr,left,span,strand) events to a
+//                      buffer and sort-reduced at finalize
 // All outputs are commutative integer sums, so any batch order gives identical
 // results.  HBM-bound integer work: no MFMA.
 #include "kernels.h"
@@ -24,8 +26,24 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kFragsPerThread = 8;
 constexpr int kChunk = kThreads * kFragsPerThread;   // fragments per workgroup iteration
-constexpr int kChrBins = 2048;      // LDS histogram covers refIDs < 1024; larger ones go straight to global
+constexpr int kChrBins = 512;       // LDS histogram covers refIDs < 256; larger ones go straight to global
+constexpr uint32_t kJCache = 512;   // LDS cache of known-junction counters (direct-mapped on the table row)
+constexpr uint32_t kEmpty = 0xffffffffu;
 constexpr uint32_t kWin = 4096;     // positions of the LDS difference-array window (per strand)
+
+// row of (gleft, span) in the known-junction keys, or -1: bucket index on gleft, then a short walk
+__device__ __forceinline__ int32_t find_known(const CountTables& T, uint64_t gleft, uint32_t span) {
+    const uint64_t key = (gleft << kJuncSpanBits) | span;
+    if (gleft >= T.plane_stride) return -1;          // malformed block: reported by the range checks
+    const uint64_t b = gleft >> kBucketShift;
+    uint32_t i = T.known_bucket[b];
+    const uint32_t i1 = T.known_bucket[b + 1];
+    for (; i < i1; i++) {
+        const uint64_t k = T.known_keys[i];
+        if (k >= key) return k == key ? (int32_t)i : -1;
+    }
+    return -1;
+}
 
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t key) {
     // first index in [lo,hi) with a[idx] >= key
@@ -37,19 +55,23 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
 }
 
 // A workgroup walks chunks of kChunk consecutive fragments.  Per chunk:
-//   1. every thread counts the junction events of its fragments; one block-wide scan and ONE global atomic reserve
-//      the chunk's slice of the event buffer (a single shared counter bumped per wave costs >15 ms at 50 M pairs);
+//   1. every thread walks the junctions of its fragments: hits on a known junction are counted in place, novel ones
+//      are counted per thread; one block-wide scan and ONE global atomic reserve the chunk's slice of the novel-event
+//      buffer (a single shared counter bumped per wave costs >15 ms at 50 M pairs);
 //   2. the fragments are processed; difference events that fall in the chunk's window [win, win + kWin) of the plane
 //      (coordinate-sorted input: nearly all of them) are accumulated in LDS, the rest go to global atomics;
 //   3. the window is flushed: one global atomic per non-zero position instead of one per event.
 __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev B) {
     __shared__ uint32_t s_chr[kChrBins];
     __shared__ int32_t s_tile[2 * kWin];
+    __shared__ uint32_t s_jtag[kJCache];
+    __shared__ uint32_t s_jcnt[2][kJCache];
     __shared__ uint32_t s_wsum[kWaves];
     __shared__ unsigned long long s_base;
     __shared__ unsigned long long s_win;
     for (int k = threadIdx.x; k < kChrBins; k += kThreads) s_chr[k] = 0;
     for (int k = threadIdx.x; k < (int)(2 * kWin); k += kThreads) s_tile[k] = 0;
+    for (int k = threadIdx.x; k < (int)kJCache; k += kThreads) { s_jtag[k] = kEmpty; s_jcnt[0][k] = 0; s_jcnt[1][k] = 0; }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -57,21 +79,43 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
     const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
     for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
         const uint32_t f0 = c * kChunk;
-        // ---- 1. junction events of this thread's fragments; window origin
-        uint32_t my_events = 0;
+        // ---- 1. junction events of this thread's fragments: known junctions are counted here, novel ones are
+        //         numbered (bit e of `novel` = this thread's e-th event is novel) so that pass 2 can place them
+        uint32_t my_events = 0, n_ev = 0;
+        uint64_t novel = 0;
         if (!(T.ablate & 8u)) {
-#pragma unroll
+#pragma unroll 1
             for (int j = 0; j < kFragsPerThread; j++) {
                 const uint32_t i = f0 + j * kThreads + threadIdx.x;
                 if (i >= B.n_frag) break;
                 const uint32_t chr = B.frag_chr[i];
                 if (chr >= T.n_chr || !T.chr_owned[chr]) continue;
+                const uint32_t dir = B.frag_flags[i] & 1u;
+                const uint64_t base = T.chr_base[chr];
                 const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
-                uint32_t prev_len = 0, prev_read = 0xffu;
+                uint32_t prev_end = 0, prev_len = 0, prev_read = 0xffu;
                 for (uint32_t k = k0; k < k1; k++) {
-                    const uint32_t bl = B.blk_len[k], rd = B.blk_read[k];
-                    my_events += (rd == prev_read && prev_len >= T.junc_min_flank && bl >= T.junc_min_flank) ? 1u : 0u;
-                    prev_len = bl; prev_read = rd;
+                    const uint32_t bs = B.blk_start[k], bl = B.blk_len[k], rd = B.blk_read[k];
+                    if (rd == prev_read && prev_len >= T.junc_min_flank && bl >= T.junc_min_flank) {
+                        const uint64_t gleft = base + prev_end;
+                        const uint32_t span = bs - prev_end;
+                        int32_t hit = -1;
+                        if (bs >= prev_end && span < (1u << kJuncSpanBits) && gleft < kJuncMaxGlobal)
+                            hit = find_known(T, gleft, span);
+                        if (hit >= 0) {
+                            // per-chunk LDS cache of the hot junctions (sorted input hits the same few again and again)
+                            const uint32_t row = T.known_kjidx[hit], c = row & (kJCache - 1);
+                            uint32_t tag = s_jtag[c];
+                            if (tag == kEmpty) { const uint32_t old = atomicCAS(&s_jtag[c], kEmpty, row); tag = old == kEmpty ? row : old; }
+                            if (tag == row) atomicAdd(&s_jcnt[dir][c], 1u);
+                            else atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + row], 1u);
+                        } else {
+                            my_events++;
+                            if (n_ev < 64u) novel |= 1ull << n_ev;
+                        }
+                        n_ev++;
+                    }
+                    prev_end = bs + bl; prev_len = bl; prev_read = rd;
                 }
             }
         }
@@ -96,6 +140,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
         __syncthreads();
         unsigned long long slot = s_base + before + incl - my_events;
         const unsigned long long win = s_win;
+        uint32_t ev_i = 0;
 
         // ---- 2. the fragments
 #pragma unroll 1
@@ -126,7 +171,6 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
             const uint32_t clen = T.chr_len[chr];
             int32_t* __restrict__ plane = T.diff + (uint64_t)dir * T.plane_stride;
             int32_t* tile = s_tile + dir * kWin;
-            const uint32_t p0 = T.sp_off[chr], p1 = T.sp_off[chr + 1];
             uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
             const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
             uint32_t prev_end = 0, prev_len = 0, prev_read = 0xffu;
@@ -145,31 +189,53 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
                 }
                 if (bs < be && !(T.ablate & 2u)) {
                     // SpansPoint
-                    if (bl > T.sp_min_len && p1 > p0) {
-                        const uint32_t lo = bs + T.sp_lo_add, hi = be - T.sp_hi_sub;
-                        for (uint32_t p = lower_bound_u32(T.sp_pos, p0, p1, lo); p < p1 && T.sp_pos[p] <= hi; p++)
-                            atomicAdd(&sp_cnt[p], 1u);
+                    if (bl > T.sp_min_len) {
+                        const uint64_t lo = base + bs + T.sp_lo_add, hi = base + be - T.sp_hi_sub;
+                        uint32_t p = T.sp_bucket[lo >> kBucketShift];
+                        const uint32_t p1 = T.sp_bucket[(hi >> kBucketShift) + 1];
+                        for (; p < p1; p++) {
+                            const uint64_t g = T.sp_gpos[p];
+                            if (g > hi) break;
+                            if (g >= lo) atomicAdd(&sp_cnt[T.sp_row[p]], 1u);
+                        }
                     }
                 }
-                // JunctionCount: gap between two consecutive blocks of the same read
+                // JunctionCount: gap between two consecutive blocks of the same read (novel junctions only; pass 1
+                // has already counted the known ones)
                 if ((rd == prev_read) && prev_len >= T.junc_min_flank && bl >= T.junc_min_flank && !(T.ablate & 8u)) {
                     const uint64_t gleft = base + prev_end;
                     const uint32_t span = bs - prev_end;
-                    if (bs < prev_end || span >= (1u << kJuncSpanBits) || gleft >= kJuncMaxGlobal) {
-                        err |= ERR_JUNC_RANGE;
-                        if (slot < T.junc_capacity) T.junc_keys[slot] = 0ull;      // keep the slot defined; the run is rejected
-                    } else if (slot >= T.junc_capacity) {
-                        err |= ERR_JUNC_CAPACITY;
-                    } else {
-                        T.junc_keys[slot] = (gleft << kJuncLeftShift) | ((uint64_t)span << 1) | dir;
+                    const bool bad = bs < prev_end || span >= (1u << kJuncSpanBits) || gleft >= kJuncMaxGlobal;
+                    bool is_novel;
+                    if (ev_i < 64u) is_novel = (novel >> ev_i) & 1ull;
+                    else is_novel = bad || find_known(T, gleft, span) < 0;
+                    ev_i++;
+                    if (is_novel) {
+                        if (bad) {
+                            err |= ERR_JUNC_RANGE;
+                            if (slot < T.junc_capacity) T.junc_keys[slot] = 0ull;      // keep the slot defined; the run is rejected
+                        } else if (slot >= T.junc_capacity) {
+                            err |= ERR_JUNC_CAPACITY;
+                        } else {
+                            T.junc_keys[slot] = (gleft << kJuncLeftShift) | ((uint64_t)span << 1) | dir;
+                        }
+                        slot++;
                     }
-                    slot++;
                 }
                 prev_end = bs + bl; prev_len = bl; prev_read = rd;
             }
         }
         __syncthreads();
-        // ---- 3. flush the window
+        // ---- 3. flush the known-junction cache and the window
+        for (uint32_t k = threadIdx.x; k < kJCache; k += kThreads) {
+            const uint32_t row = s_jtag[k];
+            if (row != kEmpty) {
+                const uint32_t c0 = s_jcnt[0][k], c1 = s_jcnt[1][k];
+                if (c0) atomicAdd(&T.known_cnt[row], c0);
+                if (c1) atomicAdd(&T.known_cnt[(uint64_t)T.n_kj + row], c1);
+                s_jtag[k] = kEmpty; s_jcnt[0][k] = 0; s_jcnt[1][k] = 0;
+            }
+        }
         for (uint32_t k = threadIdx.x; k < 2 * kWin; k += kThreads) {
             const int32_t v = s_tile[k];
             if (v) {

@@ -94,7 +94,8 @@ struct irf_ctx {
     DevBuf<uint8_t> d_chr_owned;
     DevBuf<uint32_t> d_chr_cnt;
     DevBuf<uint32_t> d_roi_off, d_roi_start, d_roi_end, d_roi_idx, d_roi_cnt;
-    DevBuf<uint32_t> d_sp_off, d_sp_pos, d_sp_cnt;
+    DevBuf<uint32_t> d_sp_row, d_sp_bucket, d_known_bucket, d_sp_cnt;
+    DevBuf<uint64_t> d_sp_gpos;
     DevBuf<uint64_t> d_junc_a, d_junc_b;
     DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
     DevBuf<uint32_t> d_err;
@@ -110,6 +111,11 @@ struct irf_ctx {
     DevBuf<int32_t> d_sp_idx_s, d_sp_idx_e, d_us_idx, d_ue_idx;
     DevBuf<uint64_t> d_us_pos, d_ue_pos, d_known_keys;
     DevBuf<uint8_t> d_known_dir;
+    DevBuf<uint32_t> d_known_kjidx, d_known_cnt;   // known-junction rows and their [2][n_kj] counters
+    DevBuf<int32_t> d_kj_idx;                      // per intron: row of (Start,End) in the known table, -1 if none
+    uint32_t n_kj = 0;
+    unsigned long long votes[2] = {0, 0};
+    uint64_t n_junction_events_total = 0;
     DevBuf<uint32_t> d_left_cnt, d_right_cnt;
     uint32_t n_us = 0, n_ue = 0, n_known_dev = 0;
     DevBuf<double> d_out_f64[2];
@@ -152,7 +158,9 @@ struct irf_ctx {
     int ensure_junc_capacity(uint64_t need);
     int submit(const irf_batch* b, uint64_t* id);
     int wait(uint64_t id);
+    void launch_stats(int t, int dirn);
     int finalize();
+    int finalize_directional(int32_t dirn);
     int fetch_results();
 };
 
@@ -288,15 +296,27 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         std::sort(key.begin(), key.end());
         sp_slot.resize(n_sp);
         sp_pos_sorted.resize(n_sp);
-        std::vector<uint32_t> offv(n + 1, 0);
+        std::vector<uint64_t> gpos;
+        std::vector<uint32_t> row;
         for (uint32_t i = 0; i < n_sp; i++) {
             sp_slot[i] = (uint32_t)(key[i] >> 32);
             sp_pos_sorted[i] = (uint32_t)key[i];
-            if (sp_slot[i] < n) offv[sp_slot[i] + 1]++;
+            const uint32_t sl = sp_slot[i];
+            if (sl < n && chr_owned[sl] && sp_pos_sorted[i] <= chr_len[sl]) { gpos.push_back(chr_base[sl] + sp_pos_sorted[i]); row.push_back(i); }
         }
-        for (uint32_t i = 0; i < n; i++) offv[i + 1] += offv[i];
-        TRY(upload(this, d_sp_off, offv));
-        TRY(upload(this, d_sp_pos, sp_pos_sorted));
+        // bucket[b] = first owned point with gpos >= b << kBucketShift
+        const uint64_t nb = (plane_stride >> dev::kBucketShift) + 2;
+        std::vector<uint32_t> bucket(nb);
+        {
+            size_t p = 0;
+            for (uint64_t b = 0; b < nb; b++) {
+                while (p < gpos.size() && gpos[p] < (b << dev::kBucketShift)) p++;
+                bucket[b] = (uint32_t)p;
+            }
+        }
+        TRY(upload(this, d_sp_gpos, gpos));
+        TRY(upload(this, d_sp_row, row));
+        TRY(upload(this, d_sp_bucket, bucket));
         TRY(alloc_zero(this, d_sp_cnt, (size_t)n_sp * 2));
     }
     // ---- known junctions sorted by (slot,left,right) ----
@@ -310,6 +330,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         kj_slot.clear(); kj_left.clear(); kj_right.clear(); kj_dir.clear();
         std::vector<uint64_t> kkeys;
         std::vector<uint8_t> kdir;
+        std::vector<uint32_t> krow;
         for (uint32_t i : idx) {
             uint32_t sl = refchr_slot[ref.kj_chr[i]];
             kj_slot.push_back(sl); kj_left.push_back(ref.kj_left[i]); kj_right.push_back(ref.kj_right[i]); kj_dir.push_back(ref.kj_dir[i]);
@@ -318,12 +339,26 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
                 if (span < (1ull << dev::kJuncSpanBits)) {
                     kkeys.push_back(((chr_base[sl] + ref.kj_left[i]) << dev::kJuncSpanBits) | span);
                     kdir.push_back(ref.kj_dir[i]);
+                    krow.push_back((uint32_t)kj_left.size() - 1);
                 }
             }
         }
         n_known_dev = (uint32_t)kkeys.size();
+        n_kj = (uint32_t)kj_left.size();
+        {
+            const uint64_t nb = (plane_stride >> dev::kBucketShift) + 2;
+            std::vector<uint32_t> bucket(nb);
+            size_t p = 0;
+            for (uint64_t b = 0; b < nb; b++) {
+                while (p < kkeys.size() && (kkeys[p] >> dev::kJuncSpanBits) < (b << dev::kBucketShift)) p++;
+                bucket[b] = (uint32_t)p;
+            }
+            TRY(upload(this, d_known_bucket, bucket));
+        }
         TRY(upload(this, d_known_keys, kkeys));
         TRY(upload(this, d_known_dir, kdir));
+        TRY(upload(this, d_known_kjidx, krow));
+        TRY(alloc_zero(this, d_known_cnt, (size_t)n_kj * 2));
     }
     // ---- introns ----
     n_intron = (uint32_t)ref.n_intron();
@@ -331,7 +366,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         std::vector<uint8_t> valid(n_intron), plus(n_intron);
         std::vector<uint64_t> gs(n_intron), ge(n_intron), bgs(ref.blk_start.size());
         std::vector<uint32_t> bl(ref.blk_start.size());
-        std::vector<int32_t> sis(n_intron, -1), sie(n_intron, -1), usi(n_intron, -1), uei(n_intron, -1);
+        std::vector<int32_t> sis(n_intron, -1), sie(n_intron, -1), usi(n_intron, -1), uei(n_intron, -1), kji(n_intron, -1);
         std::vector<uint64_t> us, ue;
         for (uint32_t i = 0; i < n_intron; i++) {
             uint32_t sl = refchr_slot[ref.in_chr[i]];
@@ -363,6 +398,16 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
                 };
                 sis[i] = find_sp(ref.in_start[i]);
                 sie[i] = find_sp(ref.in_end[i]);
+                // is (Start,End) a known junction?
+                size_t lo = 0, hi = kj_left.size();
+                const uint32_t st = ref.in_start[i], en = ref.in_end[i];
+                while (lo < hi) {
+                    size_t mid = (lo + hi) / 2;
+                    bool less = kj_slot[mid] != sl ? kj_slot[mid] < sl : (kj_left[mid] != st ? kj_left[mid] < st : kj_right[mid] < en);
+                    if (less) lo = mid + 1; else hi = mid;
+                }
+                if (lo < kj_left.size() && kj_slot[lo] == sl && kj_left[lo] == st && kj_right[lo] == en &&
+                    (uint64_t)en - st < (1ull << dev::kJuncSpanBits)) kji[i] = (int32_t)lo;
             }
         }
         std::sort(us.begin(), us.end()); us.erase(std::unique(us.begin(), us.end()), us.end());
@@ -378,7 +423,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         TRY(upload(this, d_blk_gstart, bgs)); TRY(upload(this, d_blk_len, bl));
         TRY(upload(this, d_in_measured, ref.in_measured));
         TRY(upload(this, d_sp_idx_s, sis)); TRY(upload(this, d_sp_idx_e, sie));
-        TRY(upload(this, d_us_idx, usi)); TRY(upload(this, d_ue_idx, uei));
+        TRY(upload(this, d_us_idx, usi)); TRY(upload(this, d_ue_idx, uei)); TRY(upload(this, d_kj_idx, kji));
         TRY(upload(this, d_us_pos, us)); TRY(upload(this, d_ue_pos, ue));
         TRY(alloc_zero(this, d_left_cnt, (size_t)n_us * 2));
         TRY(alloc_zero(this, d_right_cnt, (size_t)n_ue * 2));
@@ -404,6 +449,7 @@ int irf_ctx::zero_counters() {
     if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
     if (n_roi) HIP_TRY(hipMemsetAsync(d_roi_cnt.p, 0, (size_t)n_roi * 2 * sizeof(uint32_t), stream));
     if (n_sp) HIP_TRY(hipMemsetAsync(d_sp_cnt.p, 0, (size_t)n_sp * 2 * sizeof(uint32_t), stream));
+    if (n_kj) HIP_TRY(hipMemsetAsync(d_known_cnt.p, 0, (size_t)n_kj * 2 * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(d_scalars.p, 0, 8 * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), stream));
     n_fragments = n_blocks = junc_upper = 0;
@@ -429,7 +475,8 @@ dev::CountTables irf_ctx::count_tables() {
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
     T.diff = d_diff.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_off = d_roi_off.p; T.roi_start = d_roi_start.p; T.roi_end = d_roi_end.p; T.roi_idx = d_roi_idx.p; T.roi_cnt = d_roi_cnt.p;
-    T.sp_off = d_sp_off.p; T.sp_pos = d_sp_pos.p; T.sp_cnt = d_sp_cnt.p;
+    T.sp_gpos = d_sp_gpos.p; T.sp_row = d_sp_row.p; T.sp_bucket = d_sp_bucket.p; T.sp_cnt = d_sp_cnt.p;
+    T.known_keys = d_known_keys.p; T.known_bucket = d_known_bucket.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
     T.junc_keys = d_junc_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
     return T;
 }
@@ -535,6 +582,28 @@ int irf_ctx::wait(uint64_t id) {
     return 0;    // older batches were waited for when their slot was reused
 }
 
+// one IR table: t = 0 non-directional (both strands), t = 1 directional under `dirn`
+void irf_ctx::launch_stats(int t, int dirn) {
+    dev::IntronTables T;
+    memset(&T, 0, sizeof T);
+    T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
+    T.valid = d_in_valid.p; T.strand_plus = d_in_plus.p; T.g_start = d_in_gstart.p; T.g_end = d_in_gend.p;
+    T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
+    T.sp_idx_start = d_sp_idx_s.p; T.sp_idx_end = d_sp_idx_e.p; T.sp_cnt = d_sp_cnt.p;
+    T.us_idx = d_us_idx.p; T.ue_idx = d_ue_idx.p; T.left_cnt = d_left_cnt.p; T.right_cnt = d_right_cnt.p;
+    T.n_ustart = n_us; T.n_uend = n_ue;
+    T.ukeys = d_ukeys.p; T.ucount = d_ucount.p; T.n_unique = n_unique;
+    T.kj_idx = d_kj_idx.p; T.known_cnt = d_known_cnt.p; T.n_kj = n_kj;
+    T.trim_centre_pct = P.trim_centre_pct; T.pct_interpolate = P.pct_interpolate;
+    T.flank_offset = P.flank_offset; T.flank_len = P.flank_len; T.flank_use_measured = P.flank_use_measured;
+    T.directionality = dirn;
+    T.warn_lowcover_min = P.warn_lowcover_min; T.warn_lowsplice_min = P.warn_lowsplice_min;
+    T.warn_minor_ratio = P.warn_minor_ratio; T.warn_nonuniform_rel = P.warn_nonuniform_rel;
+    T.warn_nonuniform_abs = P.warn_nonuniform_abs;
+    T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
+    dev::launch_intron_stats(T, stream);
+}
+
 int irf_ctx::finalize() {
     if (!have_map) return fail(IRF_E_STATE, "irf_finalize before irf_chr_map_update");
     if (finalized) return 0;
@@ -593,17 +662,19 @@ int irf_ctx::finalize() {
     if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));
     if (n_ue) HIP_TRY(hipMemsetAsync(d_right_cnt.p, 0, (size_t)n_ue * 2 * 4, stream));
     HIP_TRY(hipMemsetAsync(d_scalars.p + 3, 0, 2 * sizeof(unsigned long long), stream));
-    if (n_unique) {
+    {
         dev::JuncLookupTables J;
         memset(&J, 0, sizeof J);
         J.ukeys = d_ukeys.p; J.ucount = d_ucount.p; J.n_unique = n_unique;
         J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
         J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
-        J.known_keys = d_known_keys.p; J.known_dir = d_known_dir.p; J.n_known = n_known_dev;
+        J.known_keys = d_known_keys.p; J.known_kjidx = d_known_kjidx.p; J.known_dir = d_known_dir.p;
+        J.n_known = n_known_dev; J.n_kj = n_kj; J.known_cnt = d_known_cnt.p;
         J.dir_votes = d_scalars.p + 3;
         dev::launch_junction_lookups(J, stream);
+        dev::launch_known_lookups(J, stream);
     }
-    unsigned long long votes[2] = {0, 0};
+    votes[0] = votes[1] = 0;
     HIP_TRY(hipMemcpyAsync(votes, d_scalars.p + 3, sizeof votes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(ev[1], stream));
     // ---- depth: one read of the difference planes -> per-segment sums -> carries (exclusive scan, in place) ----
@@ -616,26 +687,8 @@ int irf_ctx::finalize() {
     if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
     else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
     // ---- per-intron statistics and IR rows ----
-    for (int t = 0; t < 2; t++) {
-        if (t == 1 && directionality == 0) break;
-        dev::IntronTables T;
-        memset(&T, 0, sizeof T);
-        T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
-        T.valid = d_in_valid.p; T.strand_plus = d_in_plus.p; T.g_start = d_in_gstart.p; T.g_end = d_in_gend.p;
-        T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
-        T.sp_idx_start = d_sp_idx_s.p; T.sp_idx_end = d_sp_idx_e.p; T.sp_cnt = d_sp_cnt.p;
-        T.us_idx = d_us_idx.p; T.ue_idx = d_ue_idx.p; T.left_cnt = d_left_cnt.p; T.right_cnt = d_right_cnt.p;
-        T.n_ustart = n_us; T.n_uend = n_ue;
-        T.ukeys = d_ukeys.p; T.ucount = d_ucount.p; T.n_unique = n_unique;
-        T.trim_centre_pct = P.trim_centre_pct; T.pct_interpolate = P.pct_interpolate;
-        T.flank_offset = P.flank_offset; T.flank_len = P.flank_len; T.flank_use_measured = P.flank_use_measured;
-        T.directionality = t == 0 ? 0 : directionality;
-        T.warn_lowcover_min = P.warn_lowcover_min; T.warn_lowsplice_min = P.warn_lowsplice_min;
-        T.warn_minor_ratio = P.warn_minor_ratio; T.warn_nonuniform_rel = P.warn_nonuniform_rel;
-        T.warn_nonuniform_abs = P.warn_nonuniform_abs;
-        T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
-        dev::launch_intron_stats(T, stream);
-    }
+    launch_stats(0, 0);
+    if (directionality != 0) launch_stats(1, directionality);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -652,6 +705,23 @@ int irf_ctx::finalize() {
     timing.table_ms = 0;       // the IR rows are written by the statistics kernel itself
     if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) timing.total_finalize_ms = ms;
     finalized = true;
+    results_ready = false;
+    return 0;
+}
+
+// Multi-GPU: the strandedness vote must be taken over ALL shards.  The host sums irf_get_votes over the ranks,
+// decides, and imposes the decision here; the directional table is (re)computed if the local decision differed.
+int irf_ctx::finalize_directional(int32_t dirn) {
+    if (!finalized) return fail(IRF_E_STATE, "irf_finalize_directional before irf_finalize");
+    dirn = dirn > 0 ? 1 : (dirn < 0 ? -1 : 0);
+    if (dirn == directionality) return 0;
+    HIP_TRY(hipSetDevice(device));
+    directionality = dirn;
+    if (dirn != 0) {
+        launch_stats(1, dirn);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     results_ready = false;
     return 0;
 }
@@ -676,8 +746,11 @@ int irf_ctx::fetch_results() {
     h_sp_cnt = tmp;
     h_sp_chr = sp_slot;
     h_sp_pos = sp_pos_sorted;
-    // junctions: decode the unique keys, pair the two strands, merge with the known table
+    // junctions: known rows carry their in-place counters; novel unique keys are decoded, their two strands paired,
+    // and both lists (each sorted by (slot,left,right)) are merged
     {
+        std::vector<uint32_t> kc((size_t)n_kj * 2, 0u);
+        if (n_kj) HIP_TRY(hipMemcpy(kc.data(), d_known_cnt.p, kc.size() * 4, hipMemcpyDeviceToHost));
         std::vector<uint64_t> uk(n_unique);
         std::vector<uint32_t> uc(n_unique);
         if (n_unique) {
@@ -702,16 +775,17 @@ int irf_ctx::fetch_results() {
         h_j_chr.clear(); h_j_left.clear(); h_j_right.clear(); h_j_refdir.clear();
         std::vector<uint32_t> m0, m1;
         size_t a = 0, b = 0, na = oc.size(), nb = kj_left.size();
-        auto less_ab = [&](size_t i, size_t j) {      // observed[i] < known[j]
+        auto less_ab = [&](size_t i, size_t j) {      // novel[i] < known[j]
             if (oc[i] != kj_slot[j]) return oc[i] < kj_slot[j];
             if (ol[i] != kj_left[j]) return ol[i] < kj_left[j];
             return orr[i] < kj_right[j];
         };
         auto eq_ab = [&](size_t i, size_t j) { return oc[i] == kj_slot[j] && ol[i] == kj_left[j] && orr[i] == kj_right[j]; };
+        n_junction_events_total = 0;
         while (a < na || b < nb) {
-            if (a < na && b < nb && eq_ab(a, b)) {
+            if (a < na && b < nb && eq_ab(a, b)) {     // cannot happen for keys the device table holds; kept for safety
                 h_j_chr.push_back(oc[a]); h_j_left.push_back(ol[a]); h_j_right.push_back(orr[a]);
-                m0.push_back(c0[a]); m1.push_back(c1[a]); h_j_refdir.push_back(kj_dir[b]);
+                m0.push_back(c0[a] + kc[b]); m1.push_back(c1[a] + kc[(size_t)n_kj + b]); h_j_refdir.push_back(kj_dir[b]);
                 a++; b++;
             } else if (b >= nb || (a < na && less_ab(a, b))) {
                 h_j_chr.push_back(oc[a]); h_j_left.push_back(ol[a]); h_j_right.push_back(orr[a]);
@@ -719,9 +793,10 @@ int irf_ctx::fetch_results() {
                 a++;
             } else {
                 h_j_chr.push_back(kj_slot[b]); h_j_left.push_back(kj_left[b]); h_j_right.push_back(kj_right[b]);
-                m0.push_back(0); m1.push_back(0); h_j_refdir.push_back(kj_dir[b]);
+                m0.push_back(kc[b]); m1.push_back(kc[(size_t)n_kj + b]); h_j_refdir.push_back(kj_dir[b]);
                 b++;
             }
+            n_junction_events_total += (uint64_t)m0.back() + m1.back();
         }
         h_j_cnt = m0;
         h_j_cnt.insert(h_j_cnt.end(), m1.begin(), m1.end());
@@ -850,6 +925,13 @@ int irf_chr_map_update(irf_ctx* c, uint32_t n_chr, const char* const* names, con
 int irf_submit_batch(irf_ctx* c, const irf_batch* b, uint64_t* id) { return c ? c->submit(b, id) : IRF_E_ARG; }
 int irf_wait(irf_ctx* c, uint64_t id) { return c ? c->wait(id) : IRF_E_ARG; }
 int irf_finalize(irf_ctx* c) { return c ? c->finalize() : IRF_E_ARG; }
+int irf_finalize_directional(irf_ctx* c, int32_t d) { return c ? c->finalize_directional(d) : IRF_E_ARG; }
+int irf_get_votes(irf_ctx* c, uint64_t out[2]) {
+    if (!c || !out) return IRF_E_ARG;
+    if (!c->finalized) return c->fail(IRF_E_STATE, "irf_get_votes before irf_finalize");
+    out[0] = c->votes[0]; out[1] = c->votes[1];
+    return 0;
+}
 
 int irf_reset(irf_ctx* c) {
     if (!c) return IRF_E_ARG;
@@ -884,7 +966,7 @@ int irf_get_results(irf_ctx* c, irf_results* out) {
         T.sp_left = u; T.sp_right = u + n; T.splice_left = u + 2 * n; T.splice_right = u + 3 * n; T.splice_exact = u + 4 * n;
         T.warning = c->h_warn[t].data();
     }
-    out->n_fragments = c->n_fragments; out->n_blocks = c->n_blocks; out->n_junction_events = c->n_events;
+    out->n_fragments = c->n_fragments; out->n_blocks = c->n_blocks; out->n_junction_events = c->n_junction_events_total;
     return 0;
 }
 
@@ -937,6 +1019,7 @@ int irf_export_device(irf_ctx* c, uint32_t what, void* dst, uint64_t* n_out) {
         case IRF_COL_SP_CNT: src = c->d_sp_cnt.p; n = (uint64_t)c->n_sp * 2; break;
         case IRF_COL_ROI_CNT: src = c->d_roi_cnt.p; n = (uint64_t)c->n_roi * 2; break;
         case IRF_COL_CHR_CNT: src = c->d_chr_cnt.p; n = (uint64_t)c->n_chr * 2; break;
+        case IRF_COL_KNOWN_CNT: src = c->d_known_cnt.p; n = (uint64_t)c->n_kj * 2; break;
         default: return c->fail(IRF_E_ARG, "irf_export_device: unknown column");
     }
     *n_out = n;

@@ -16,6 +16,7 @@ namespace dev {
 constexpr int kJuncSpanBits = 28;
 constexpr int kJuncLeftShift = kJuncSpanBits + 1;
 constexpr uint64_t kJuncMaxGlobal = 1ull << 34;
+constexpr int kBucketShift = 9;     // 512-position buckets of the plane for the point / known-junction indices
 
 enum ErrBits : uint32_t {
     ERR_CHR_RANGE = 1u,        // frag_chr >= n_chr
@@ -46,10 +47,22 @@ struct CountTables {
     const uint32_t* roi_end;
     const uint32_t* roi_idx;   // file index of the sorted ROI
     uint32_t* roi_cnt;         // [2][n_roi]
-    const uint32_t* sp_off;    // [n_chr+1] into the (chr,pos)-sorted points
-    const uint32_t* sp_pos;
+    // SpansPoint: points on owned chromosomes in plane coordinates + a bucket index over the plane
+    // (sp_bucket[b] = first point with gpos >= b << kBucketShift), so a block costs two adjacent loads when no
+    // point is near (the common case) instead of a 19-step binary search
+    const uint64_t* sp_gpos;   // [n_sp_own] sorted
+    const uint32_t* sp_row;    // [n_sp_own] row in sp_cnt
+    const uint32_t* sp_bucket; // [plane_stride >> kBucketShift) + 2]
     uint32_t* sp_cnt;          // [2][n_sp]
-    uint64_t* junc_keys;       // event buffer
+    // known junctions (ref-sj.ref) on owned chromosomes: events that hit one are counted in place,
+    // only novel junctions go through the event buffer + sort
+    const uint64_t* known_keys;   // sorted (global_left << 28 | span)
+    const uint32_t* known_bucket; // [(plane_stride >> kBucketShift) + 2] first known key with global_left >= b << kBucketShift
+    const uint32_t* known_kjidx;  // row of the known-junction table (all of ref-sj, (slot,left,right) order)
+    uint32_t n_known;             // entries of known_keys
+    uint32_t n_kj;                // rows of the known-junction table
+    uint32_t* known_cnt;          // [2][n_kj]
+    uint64_t* junc_keys;          // novel-junction event buffer
     unsigned long long* junc_count;
     uint32_t* err_flags;
 };
@@ -103,12 +116,18 @@ struct JuncLookupTables {
     uint32_t n_ustart, n_uend;
     uint32_t* left_cnt;          // [2][n_ustart]   SpliceLeft by strand
     uint32_t* right_cnt;         // [2][n_uend]
-    const uint64_t* known_keys;  // sorted (global_left << 28 | span) of ref-sj junctions on BAM chromosomes
-    const uint8_t* known_dir;
-    uint32_t n_known;
-    unsigned long long* dir_votes;   // [2]: same, opposite
+    // known junctions: counted in place by the count kernel
+    const uint64_t* known_keys;  // sorted (global_left << 28 | span) of ref-sj junctions on owned chromosomes
+    const uint32_t* known_kjidx;
+    const uint8_t* known_dir;    // per known_keys entry: 1 '-', 2 '+', 0/3 unknown
+    uint32_t n_known, n_kj;
+    const uint32_t* known_cnt;   // [2][n_kj]
+    unsigned long long* dir_votes;   // [2]: same, opposite (JunctionCount::Directional)
 };
+// novel unique junctions -> SpliceLeft/Right counters
 void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s);
+// known junctions -> SpliceLeft/Right counters + the Directional() vote
+void launch_known_lookups(const JuncLookupTables& J, hipStream_t s);
 
 // ---- per-intron statistics + IR table --------------------------------------------
 struct IntronTables {
@@ -133,9 +152,13 @@ struct IntronTables {
     const uint32_t* left_cnt;
     const uint32_t* right_cnt;
     uint32_t n_ustart, n_uend;
-    const uint64_t* ukeys;
+    const uint64_t* ukeys;         // novel unique junctions
     const uint32_t* ucount;
     uint64_t n_unique;
+    const int32_t* kj_idx;         // [n_intron] row of the known-junction table for (Start,End), -1 if not in ref-sj
+    const uint32_t* known_cnt;     // [2][n_kj]
+    uint32_t n_kj;
+    uint32_t pad1;
     // parameters
     uint32_t trim_centre_pct, pct_interpolate, flank_offset, flank_len, flank_use_measured;
     int32_t directionality;        // 0: non-directional table (both planes)

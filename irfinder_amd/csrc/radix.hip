@@ -4,11 +4,14 @@
 // ReadBlockProcessor.cpp JunctionCount::ProcessBlocks (RB-tree insert per
 // event) with: append packed 64-bit (chr+left, span, strand) events during
 // counting, then one stable LSD radix sort (8-bit digits, constant digits
-// skipped) + run-length reduction at finalize.  juncLeft / juncRight are not
+// skipped) + run-length reduction at finalize — for NOVEL junctions; reads on a
+// junction listed in ref-sj.ref (the vast majority) are counted in place by the
+// count kernel and never enter the sort.  juncLeft / juncRight are not
 // materialised as maps: their only consumers are the lookups at intron Start /
 // End (CoverageBlocksIRFinder::WriteOutput), so the unique junctions are
-// scattered once into per-intron-boundary counters (launch_junction_lookups).
-// The same kernel takes the Directional() vote against the known-junction table.
+// scattered once into per-intron-boundary counters (launch_junction_lookups for
+// the novel table, launch_known_lookups for the known one, which also takes the
+// Directional() vote).
 #include "kernels.h"
 
 namespace irf {
@@ -133,24 +136,46 @@ __device__ __forceinline__ int64_t find_u64(const uint64_t* __restrict__ a, uint
     return (lo < n && a[lo] == key) ? (int64_t)lo : -1;
 }
 
+// novel unique junctions -> SpliceLeft / SpliceRight counters of the intron boundaries they touch
 __global__ __launch_bounds__(kThreads) void junction_lookups_kernel(JuncLookupTables J) {
-    unsigned long long same = 0, opp = 0;
     const uint64_t u = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (u < J.n_unique) {
-        const uint64_t key = J.ukeys[u];
-        const uint32_t cnt = J.ucount[u];
-        const uint32_t dir = (uint32_t)(key & 1ull);
-        const uint64_t gleft = key >> kJuncLeftShift;
-        const uint64_t span = (key >> 1) & ((1ull << kJuncSpanBits) - 1ull);
-        int64_t a = find_u64(J.ustart_pos, J.n_ustart, gleft);
-        if (a >= 0) atomicAdd(&J.left_cnt[(uint64_t)dir * J.n_ustart + (uint64_t)a], cnt);
-        int64_t b = find_u64(J.uend_pos, J.n_uend, gleft + span);
-        if (b >= 0) atomicAdd(&J.right_cnt[(uint64_t)dir * J.n_uend + (uint64_t)b], cnt);
-        int64_t k = find_u64(J.known_keys, J.n_known, key >> 1);
-        if (k >= 0) {
+    if (u >= J.n_unique) return;
+    const uint64_t key = J.ukeys[u];
+    const uint32_t cnt = J.ucount[u];
+    const uint32_t dir = (uint32_t)(key & 1ull);
+    const uint64_t gleft = key >> kJuncLeftShift;
+    const uint64_t span = (key >> 1) & ((1ull << kJuncSpanBits) - 1ull);
+    const int64_t a = find_u64(J.ustart_pos, J.n_ustart, gleft);
+    if (a >= 0) atomicAdd(&J.left_cnt[(uint64_t)dir * J.n_ustart + (uint64_t)a], cnt);
+    const int64_t b = find_u64(J.uend_pos, J.n_uend, gleft + span);
+    if (b >= 0) atomicAdd(&J.right_cnt[(uint64_t)dir * J.n_uend + (uint64_t)b], cnt);
+}
+
+// known junctions (counted in place by the count kernel) -> the same counters, plus the strandedness vote of
+// JunctionCount::Directional(): reads on a junction of known strand agree ("same") or disagree ("opposite") with it
+__global__ __launch_bounds__(kThreads) void known_lookups_kernel(JuncLookupTables J) {
+    unsigned long long same = 0, opp = 0;
+    const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
+    if (k < J.n_known) {
+        const uint32_t row = J.known_kjidx[k];
+        const uint32_t c0 = J.known_cnt[row], c1 = J.known_cnt[(uint64_t)J.n_kj + row];
+        if (c0 | c1) {
+            const uint64_t key = J.known_keys[k];
+            const uint64_t gleft = key >> kJuncSpanBits;
+            const uint64_t span = key & ((1ull << kJuncSpanBits) - 1ull);
+            const int64_t a = find_u64(J.ustart_pos, J.n_ustart, gleft);
+            if (a >= 0) {
+                if (c0) atomicAdd(&J.left_cnt[(uint64_t)a], c0);
+                if (c1) atomicAdd(&J.left_cnt[(uint64_t)J.n_ustart + (uint64_t)a], c1);
+            }
+            const int64_t b = find_u64(J.uend_pos, J.n_uend, gleft + span);
+            if (b >= 0) {
+                if (c0) atomicAdd(&J.right_cnt[(uint64_t)b], c0);
+                if (c1) atomicAdd(&J.right_cnt[(uint64_t)J.n_uend + (uint64_t)b], c1);
+            }
             const uint32_t kd = J.known_dir[k];
-            if (kd == 1u) { if (dir == 0) same += cnt; else opp += cnt; }
-            else if (kd == 2u) { if (dir == 1) same += cnt; else opp += cnt; }
+            if (kd == 1u) { same += c0; opp += c1; }
+            else if (kd == 2u) { same += c1; opp += c0; }
         }
     }
 #pragma unroll
@@ -207,6 +232,11 @@ void launch_run_lengths(const uint32_t* ustart, uint64_t nu, uint64_t n, uint32_
 void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s) {
     if (J.n_unique == 0) return;
     hipLaunchKernelGGL(junction_lookups_kernel, dim3(blocks_for(J.n_unique)), dim3(kThreads), 0, s, J);
+}
+
+void launch_known_lookups(const JuncLookupTables& J, hipStream_t s) {
+    if (J.n_known == 0) return;
+    hipLaunchKernelGGL(known_lookups_kernel, dim3(blocks_for(J.n_known)), dim3(kThreads), 0, s, J);
 }
 
 }   // namespace dev

@@ -388,8 +388,11 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
             const int32_t us = T.us_idx[i], ue = T.ue_idx[i];
             if (us >= 0) jl = plane == 2 ? T.left_cnt[us] + T.left_cnt[(uint64_t)T.n_ustart + us] : T.left_cnt[(uint64_t)plane * T.n_ustart + us];
             if (ue >= 0) jr = plane == 2 ? T.right_cnt[ue] + T.right_cnt[(uint64_t)T.n_uend + ue] : T.right_cnt[(uint64_t)plane * T.n_uend + ue];
+            const int32_t kj = T.kj_idx[i];
             const uint64_t span = gE - gS;
-            if (span < (1ull << kJuncSpanBits) && gS < kJuncMaxGlobal && T.n_unique > 0) {
+            if (kj >= 0) {          // (Start,End) is a ref-sj junction: its reads were counted in place
+                je = plane == 2 ? T.known_cnt[kj] + T.known_cnt[(uint64_t)T.n_kj + kj] : T.known_cnt[(uint64_t)plane * T.n_kj + kj];
+            } else if (span < (1ull << kJuncSpanBits) && gS < kJuncMaxGlobal && T.n_unique > 0) {
                 const uint64_t key0 = (gS << kJuncLeftShift) | (span << 1);
                 uint64_t lo_i = 0, hi_i = T.n_unique;
                 while (lo_i < hi_i) {

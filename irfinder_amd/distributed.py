@@ -68,12 +68,14 @@ def gather_tables(tables, dist=None, root=0):
     """Collect the per-rank result tables on `root`.
 
     tables: dict of torch tensors on the rank's device —
-        fixed shape, zero where not owned: 'ir_f64' [8,n], 'ir_u32' [6,n] (int32 view), 'sp_cnt', 'roi_cnt', 'chr_cnt'
-        variable length:                   'junc_keys' (int64 view of the packed keys), 'junc_counts' (int32)
+        fixed shape, zero where not owned: 'ir_f64' [8,n], 'ir_u32' [6,n] (int32 view), 'sp_cnt', 'roi_cnt', 'chr_cnt',
+                                           'known_cnt' [2,n_ref_junction] (reads on ref-sj junctions)
+        variable length (novel junctions): 'junc_keys' (int64 view of the packed keys), 'junc_counts' (int32)
     Returns on root: dict with the summed fixed tables and 'junc_keys'/'junc_counts' as lists (one entry per rank);
     on other ranks: None.  With dist None (single process) the input is returned in the same shape."""
     import torch
-    fixed = [k for k in ("ir_f64", "ir_u32", "ir_dir_f64", "ir_dir_u32", "sp_cnt", "roi_cnt", "chr_cnt") if k in tables]
+    fixed = [k for k in ("ir_f64", "ir_u32", "ir_dir_f64", "ir_dir_u32", "sp_cnt", "roi_cnt", "chr_cnt", "known_cnt")
+             if k in tables]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         out = {k: tables[k] for k in fixed}
         out["junc_keys"] = [tables["junc_keys"]]
@@ -101,6 +103,19 @@ def gather_tables(tables, dist=None, root=0):
         else:
             dist.gather(pad, None, dst=root)
     return out if rank == root else None
+
+
+def global_directionality(votes, dist=None, ratio=10):
+    """JunctionCount::Directional() over all shards: all-reduce(SUM) of the per-rank votes (same, opposite), then the
+    same rule the engine applies locally.  votes: int64 tensor of 2 elements on the rank's device."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(votes, op=dist.ReduceOp.SUM)
+    same, opp = int(votes[0].item()), int(votes[1].item())
+    if same > opp * ratio:
+        return 1
+    if opp > same * ratio:
+        return -1
+    return 0
 
 
 def mask_unowned_rows(ir_f64, ir_u32, intron_owned):

@@ -70,6 +70,8 @@ def lib():
     L.irf_submit_batch.argtypes = [vp, C.POINTER(IrfBatch), C.POINTER(u64)]
     L.irf_wait.argtypes = [vp, u64]
     L.irf_finalize.argtypes = [vp]
+    L.irf_finalize_directional.argtypes = [vp, C.c_int32]
+    L.irf_get_votes.argtypes = [vp, C.POINTER(u64)]
     L.irf_get_results.argtypes = [vp, C.POINTER(IrfResults)]
     L.irf_chr_name.argtypes = [vp, u32]
     L.irf_chr_name.restype = C.c_char_p
@@ -267,6 +269,14 @@ class Engine:
 
     def finalize(self):
         self._chk(self.L.irf_finalize(self.h))
+
+    def votes(self):
+        v = (C.c_uint64 * 2)()
+        self._chk(self.L.irf_get_votes(self.h, v))
+        return int(v[0]), int(v[1])
+
+    def finalize_directional(self, directionality):
+        self._chk(self.L.irf_finalize_directional(self.h, int(directionality)))
 
     def reset(self):
         self._chk(self.L.irf_reset(self.h))

@@ -115,6 +115,24 @@ def test_oq_switches(over):
     assert_results_equal(g, c, rel=0.0, what=str(over))
 
 
+def test_novel_junctions_and_many_events_per_thread():
+    """Half of ref-sj.ref removed (those junctions become NOVEL: event buffer + radix sort-reduce), plus reads with
+    100 junctions each (more events per thread than the 64-bit novel mask holds), alternating known / novel."""
+    ann, sim = small_world(seed=14, stranded=True)
+    names, lens, batch = read_batch(sim.bam(0, 30000))
+    sj = "".join(l for i, l in enumerate(ann.sj_ref.splitlines(True)) if i % 2 == 0)
+    # a comb of 101 blocks on chrT1: junction k spans [1000+16k+6, 1000+16k+16)
+    comb_known = "".join("chrT1\t%d\t%d\t+\n" % (1000 + 16 * k + 6, 1000 + 16 * k + 16) for k in range(0, 100, 2))
+    recs = [dict(ref_id=0, pos=1000, flag=0x10 if i % 2 else 0, cigar="6M10N" * 100 + "6M") for i in range(700)]
+    n2, l2, comb = read_batch(records_to_bam(names, lens, recs))
+    refs = (ann.cover_bed, sj + comb_known, ann.read_continues_ref, ann.roi_bed)
+    e, g = run_gpu(refs, names, lens, split(batch, 2) + [comb])
+    o, c = run_orc(refs, names, lens, [batch, comb])
+    assert_results_equal(g, c, rel=0.0, what="novel")
+    novel = (g["junc_refdir"] == 0) & (g["junc_cnt"].sum(axis=0) > 0)
+    assert novel.sum() > 50 and g["junc_cnt"][:, novel].sum() > 5000
+
+
 COVER = ("chrA\t1000\t3000\tG/E/+/1/1000/3000/clean\t0\t+\t1000\t3000\t0\t2\t600,900\t0,1100\n"
          "chrA\t5000\t5040\tH/E/-/1/5000/5040/clean\t0\t-\t5000\t5040\t0\t1\t40\t0\n"
          "chrZ\t10\t500\tZ/E/+/1/10/500/clean\t0\t+\t10\t500\t0\t1\t490\t0\n"
