@@ -29,12 +29,13 @@ constexpr int kChunk = kThreads * kFragsPerThread;   // fragments per workgroup 
 constexpr int kChrBins = 512;       // LDS histogram covers refIDs < 256; larger ones go straight to global
 constexpr uint32_t kJCache = 512;   // LDS cache of known-junction counters (direct-mapped on the table row)
 constexpr uint32_t kEmpty = 0xffffffffu;
+constexpr uint32_t kECache = 1024;  // LDS cache of difference events outside the window (direct-mapped on plane address)
 constexpr uint32_t kWin = 4096;     // positions of the LDS difference-array window (per strand)
 
 // row of (gleft, span) in the known-junction keys, or -1: bucket index on gleft, then a short walk
 __device__ __forceinline__ int32_t find_known(const CountTables& T, uint64_t gleft, uint32_t span) {
     const uint64_t key = (gleft << kJuncSpanBits) | span;
-    if (gleft >= T.plane_stride) return -1;          // malformed block: reported by the range checks
+    if (gleft >= T.full_size) return -1;             // malformed block: reported by the range checks
     const uint64_t b = gleft >> kBucketShift;
     uint32_t i = T.known_bucket[b];
     const uint32_t i1 = T.known_bucket[b + 1];
@@ -43,6 +44,18 @@ __device__ __forceinline__ int32_t find_known(const CountTables& T, uint64_t gle
         if (k >= key) return k == key ? (int32_t)i : -1;
     }
     return -1;
+}
+
+// A difference event outside the chunk's window (typically the far side of a splice: many reads of a chunk share
+// the same exon boundary).  Direct-mapped LDS cache on the plane address; a slot held by another address falls
+// through to a global atomic.
+__device__ __forceinline__ void far_event(const CountTables& T, uint32_t* s_etag, int32_t* s_ecnt, uint64_t g, uint32_t dir, int v) {
+    const uint64_t gd = g * 2u + dir;
+    const uint32_t c = (uint32_t)gd & (kECache - 1), want = (uint32_t)(gd >> 10);
+    uint32_t tag = s_etag[c];
+    if (tag == kEmpty) { const uint32_t old = atomicCAS(&s_etag[c], kEmpty, want); tag = old == kEmpty ? want : old; }
+    if (tag == want) atomicAdd(&s_ecnt[c], v);
+    else __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t key) {
@@ -58,12 +71,15 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
 //   1. every thread walks the junctions of its fragments: hits on a known junction are counted in place, novel ones
 //      are counted per thread; one block-wide scan and ONE global atomic reserve the chunk's slice of the novel-event
 //      buffer (a single shared counter bumped per wave costs >15 ms at 50 M pairs);
-//   2. the fragments are processed; difference events that fall in the chunk's window [win, win + kWin) of the plane
+//   2. the fragments are processed; difference events are mapped to plane coordinates (kernels.h: plane_coord); those
+//      that fall in the chunk's window [win, win + kWin) of the plane
 //      (coordinate-sorted input: nearly all of them) are accumulated in LDS, the rest go to global atomics;
 //   3. the window is flushed: one global atomic per non-zero position instead of one per event.
 __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev B) {
     __shared__ uint32_t s_chr[kChrBins];
     __shared__ int32_t s_tile[2 * kWin];
+    __shared__ uint32_t s_etag[kECache];
+    __shared__ int32_t s_ecnt[kECache];
     __shared__ uint32_t s_jtag[kJCache];
     __shared__ uint32_t s_jcnt[2][kJCache];
     __shared__ uint32_t s_wsum[kWaves];
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
     __shared__ unsigned long long s_win;
     for (int k = threadIdx.x; k < kChrBins; k += kThreads) s_chr[k] = 0;
     for (int k = threadIdx.x; k < (int)(2 * kWin); k += kThreads) s_tile[k] = 0;
+    for (int k = threadIdx.x; k < (int)kECache; k += kThreads) { s_etag[k] = kEmpty; s_ecnt[k] = 0; }
     for (int k = threadIdx.x; k < (int)kJCache; k += kThreads) { s_jtag[k] = kEmpty; s_jcnt[0][k] = 0; s_jcnt[1][k] = 0; }
     __syncthreads();
 
@@ -129,7 +146,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
         if (threadIdx.x == 0) {
             const uint32_t chr = B.frag_chr[f0];
             unsigned long long w = 0;
-            if (chr < T.n_chr) w = (T.chr_base[chr] + B.frag_start[f0]) & ~63ull;
+            if (chr < T.n_chr && T.chr_owned[chr] && B.frag_start[f0] <= T.chr_len[chr])
+                w = plane_coord(T.pmap, T.chr_base[chr] + B.frag_start[f0]) & ~63ull;
             s_win = w;
         }
         __syncthreads();
@@ -169,7 +187,6 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
             // per aligned block
             const uint64_t base = T.chr_base[chr];
             const uint32_t clen = T.chr_len[chr];
-            int32_t* __restrict__ plane = T.diff + (uint64_t)dir * T.plane_stride;
             int32_t* tile = s_tile + dir * kWin;
             uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
             const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
@@ -180,12 +197,12 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
                 if (be > clen || be < bs) { err |= ERR_BLOCK_RANGE; be = clen; }
                 if (bs < be && !(T.ablate & 1u)) {
                     // CoverageBlocks / FragmentsMap: difference events, LDS window first
-                    const uint64_t gs = base + bs, ge = base + be;
+                    const uint64_t gs = plane_coord(T.pmap, base + bs), ge = plane_coord(T.pmap, base + be);
                     const uint64_t os = gs - win, oe = ge - win;
                     if (os < kWin) atomicAdd(&tile[os], 1);
-                    else __hip_atomic_fetch_add(plane + gs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else far_event(T, s_etag, s_ecnt, gs, dir, 1);
                     if (oe < kWin) atomicAdd(&tile[oe], -1);
-                    else __hip_atomic_fetch_add(plane + ge, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else far_event(T, s_etag, s_ecnt, ge, dir, -1);
                 }
                 if (bs < be && !(T.ablate & 2u)) {
                     // SpansPoint
@@ -226,7 +243,16 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
             }
         }
         __syncthreads();
-        // ---- 3. flush the known-junction cache and the window
+        // ---- 3. flush the far-event cache, the known-junction cache and the window
+        for (uint32_t k = threadIdx.x; k < kECache; k += kThreads) {
+            const uint32_t tag = s_etag[k];
+            if (tag != kEmpty) {
+                const int32_t v = s_ecnt[k];
+                const uint64_t gd = ((uint64_t)tag << 10) | k;
+                if (v) __hip_atomic_fetch_add(T.diff + (gd & 1u) * T.plane_stride + (gd >> 1), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_etag[k] = kEmpty; s_ecnt[k] = 0;
+            }
+        }
         for (uint32_t k = threadIdx.x; k < kJCache; k += kThreads) {
             const uint32_t row = s_jtag[k];
             if (row != kEmpty) {

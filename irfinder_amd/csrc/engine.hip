@@ -84,7 +84,11 @@ struct irf_ctx {
     std::vector<uint8_t> chr_owned;
     std::vector<uint64_t> chr_base;              // per BAM reference, offset inside a plane
     std::vector<uint32_t> refchr_slot;           // reference chr id -> slot
-    uint64_t plane_stride = 0;
+    uint64_t plane_stride = 0;                   // positions per strand plane (compact unless keep_depth)
+    uint64_t full_size = 0;                      // full coordinate space: sum of owned (len+1, rounded to 64)
+    std::vector<uint32_t> pmap;                  // full -> plane, per 512-bucket; empty = identity
+    DevBuf<uint32_t> d_pmap;
+    DevBuf<uint64_t> d_blk_cstart;
 
     // ---- device state ----
     DevBuf<int32_t> d_diff;
@@ -252,8 +256,46 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         chr_base[i] = off;
         if (chr_owned[i]) off += (((uint64_t)chr_len[i] + 1 + 63) / 64) * 64;
     }
-    plane_stride = ((off + dev::kScanTile - 1) / dev::kScanTile) * dev::kScanTile;     // whole scan tiles / depth segments
-    if (plane_stride >= dev::kJuncMaxGlobal) return fail(IRF_E_RANGE, "genome too large for the packed junction key (>= 2^34 bases)");
+    full_size = ((off + dev::kScanTile - 1) / dev::kScanTile) * dev::kScanTile;
+    if (full_size >= dev::kJuncMaxGlobal) return fail(IRF_E_RANGE, "genome too large for the packed junction key (>= 2^34 bases)");
+    // which introns can be measured at all (chromosome in the BAM header, owned, coordinates inside it)
+    n_intron = (uint32_t)ref.n_intron();
+    std::vector<uint8_t> in_valid(n_intron);
+    for (uint32_t i = 0; i < n_intron; i++) {
+        uint32_t sl = refchr_slot[ref.in_chr[i]];
+        bool ok = sl < n && chr_owned[sl] && ref.in_end[i] <= chr_len[sl] && ref.in_start[i] <= ref.in_end[i];
+        for (uint32_t b = ref.in_blk_off[i]; ok && b < ref.in_blk_off[i + 1]; b++)
+            if (ref.blk_end[b] > chr_len[sl] || ref.blk_end[b] < ref.blk_start[b]) ok = false;
+        in_valid[i] = ok;
+    }
+    // plane layout: the whole coordinate space (keep_depth: FragmentsMap), or only the 512-position buckets that hold
+    // measured intron bases (kernels.h: plane_coord)
+    pmap.clear();
+    plane_stride = full_size;
+    if (!P.keep_depth) {
+        const uint64_t nbk = (full_size >> dev::kBucketShift) + 2;
+        std::vector<uint8_t> keep(nbk, 0);
+        auto mark = [&](uint64_t g0, uint64_t g1) {          // [g0, g1)
+            if (g0 >= g1) return;
+            for (uint64_t b = g0 >> dev::kBucketShift; b <= (g1 - 1) >> dev::kBucketShift; b++) keep[b] = 1;
+        };
+        for (uint32_t i = 0; i < n_intron; i++) {
+            if (!in_valid[i]) continue;
+            const uint64_t base = chr_base[refchr_slot[ref.in_chr[i]]];
+            for (uint32_t b = ref.in_blk_off[i]; b < ref.in_blk_off[i + 1]; b++) mark(base + ref.blk_start[b], base + ref.blk_end[b]);
+            if (!P.flank_use_measured) {
+                const uint64_t st = ref.in_start[i], en = ref.in_end[i], il = en - st, fo = P.flank_offset, fl = P.flank_len;
+                mark(base + st + std::min(fo, il), base + st + std::min(fo + fl, il));
+                mark(base + en - std::min(fo + fl, il), base + en - std::min(fo, il));
+            }
+        }
+        pmap.resize(nbk);
+        uint64_t kept = 0;
+        for (uint64_t b = 0; b < nbk; b++) { pmap[b] = (uint32_t)((kept << 1) | keep[b]); kept += keep[b]; }
+        if (kept >= (1ull << 30)) { pmap.clear(); }          // does not fit the map encoding: fall back to full planes
+        else plane_stride = (((kept << dev::kBucketShift) + 1 + dev::kScanTile - 1) / dev::kScanTile) * dev::kScanTile;
+    }
+    TRY(upload(this, d_pmap, pmap));
     TRY(upload(this, d_chr_base, chr_base));
     TRY(upload(this, d_chr_len, chr_len));
     TRY(upload(this, d_chr_owned, chr_owned));
@@ -305,7 +347,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             if (sl < n && chr_owned[sl] && sp_pos_sorted[i] <= chr_len[sl]) { gpos.push_back(chr_base[sl] + sp_pos_sorted[i]); row.push_back(i); }
         }
         // bucket[b] = first owned point with gpos >= b << kBucketShift
-        const uint64_t nb = (plane_stride >> dev::kBucketShift) + 2;
+        const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
         std::vector<uint32_t> bucket(nb);
         {
             size_t p = 0;
@@ -346,7 +388,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         n_known_dev = (uint32_t)kkeys.size();
         n_kj = (uint32_t)kj_left.size();
         {
-            const uint64_t nb = (plane_stride >> dev::kBucketShift) + 2;
+            const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
             std::vector<uint32_t> bucket(nb);
             size_t p = 0;
             for (uint64_t b = 0; b < nb; b++) {
@@ -361,25 +403,24 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         TRY(alloc_zero(this, d_known_cnt, (size_t)n_kj * 2));
     }
     // ---- introns ----
-    n_intron = (uint32_t)ref.n_intron();
     {
-        std::vector<uint8_t> valid(n_intron), plus(n_intron);
+        std::vector<uint8_t> valid(in_valid), plus(n_intron);
+        std::vector<uint64_t> bcs(ref.blk_start.size());
+        const uint32_t* pm = pmap.empty() ? nullptr : pmap.data();
         std::vector<uint64_t> gs(n_intron), ge(n_intron), bgs(ref.blk_start.size());
         std::vector<uint32_t> bl(ref.blk_start.size());
         std::vector<int32_t> sis(n_intron, -1), sie(n_intron, -1), usi(n_intron, -1), uei(n_intron, -1), kji(n_intron, -1);
         std::vector<uint64_t> us, ue;
         for (uint32_t i = 0; i < n_intron; i++) {
             uint32_t sl = refchr_slot[ref.in_chr[i]];
-            bool ok = sl < n && chr_owned[sl] && ref.in_end[i] <= chr_len[sl];
-            for (uint32_t b = ref.in_blk_off[i]; ok && b < ref.in_blk_off[i + 1]; b++)
-                if (ref.blk_end[b] > chr_len[sl] || ref.blk_end[b] < ref.blk_start[b]) ok = false;
-            valid[i] = ok;
+            const bool ok = valid[i] != 0;
             plus[i] = ref.in_strand[i] != '-';
             uint64_t base = ok ? chr_base[sl] : 0;
             gs[i] = base + ref.in_start[i];
             ge[i] = base + ref.in_end[i];
             for (uint32_t b = ref.in_blk_off[i]; b < ref.in_blk_off[i + 1]; b++) {
                 bgs[b] = base + ref.blk_start[b];
+                bcs[b] = ok ? dev::plane_coord(pm, bgs[b]) : bgs[b];
                 bl[b] = ref.blk_end[b] >= ref.blk_start[b] ? ref.blk_end[b] - ref.blk_start[b] : 0;
             }
             if (ok) {
@@ -420,7 +461,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         TRY(upload(this, d_in_valid, valid)); TRY(upload(this, d_in_plus, plus));
         TRY(upload(this, d_in_gstart, gs)); TRY(upload(this, d_in_gend, ge));
         TRY(upload(this, d_in_blk_off, ref.in_blk_off));
-        TRY(upload(this, d_blk_gstart, bgs)); TRY(upload(this, d_blk_len, bl));
+        TRY(upload(this, d_blk_gstart, bgs)); TRY(upload(this, d_blk_cstart, bcs)); TRY(upload(this, d_blk_len, bl));
         TRY(upload(this, d_in_measured, ref.in_measured));
         TRY(upload(this, d_sp_idx_s, sis)); TRY(upload(this, d_sp_idx_e, sie));
         TRY(upload(this, d_us_idx, usi)); TRY(upload(this, d_ue_idx, uei)); TRY(upload(this, d_kj_idx, kji));
@@ -470,7 +511,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.sp_lo_add = P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u);
     T.sp_hi_sub = P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u);
     { const char* ab = getenv("IRF_ABLATE"); T.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
-    T.plane_stride = plane_stride;
+    T.plane_stride = plane_stride; T.full_size = full_size; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
     T.junc_capacity = d_junc_a.cap;
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
     T.diff = d_diff.p; T.chr_cnt = d_chr_cnt.p;
@@ -588,7 +629,7 @@ void irf_ctx::launch_stats(int t, int dirn) {
     memset(&T, 0, sizeof T);
     T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
     T.valid = d_in_valid.p; T.strand_plus = d_in_plus.p; T.g_start = d_in_gstart.p; T.g_end = d_in_gend.p;
-    T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
+    T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_cstart = d_blk_cstart.p; T.pmap = pmap.empty() ? nullptr : d_pmap.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
     T.sp_idx_start = d_sp_idx_s.p; T.sp_idx_end = d_sp_idx_e.p; T.sp_cnt = d_sp_cnt.p;
     T.us_idx = d_us_idx.p; T.ue_idx = d_ue_idx.p; T.left_cnt = d_left_cnt.p; T.right_cnt = d_right_cnt.p;
     T.n_ustart = n_us; T.n_uend = n_ue;
@@ -978,6 +1019,7 @@ uint32_t irf_n_chr_slots(const irf_ctx* c) { return c ? (uint32_t)c->slot_names.
 int irf_get_depth(irf_ctx* c, uint32_t chr, uint32_t start, uint32_t end, uint32_t dir, uint32_t* out) {
     if (!c || !out) return IRF_E_ARG;
     if (!c->finalized) return c->fail(IRF_E_STATE, "irf_get_depth before irf_finalize");
+    if (!c->pmap.empty()) return c->fail(IRF_E_STATE, "irf_get_depth needs params.keep_depth = 1 (the default keeps only the measured intron regions in HBM)");
     if (chr >= c->n_chr || !c->chr_owned[chr] || start > end || end > c->chr_len[chr] || dir > 2) return c->fail(IRF_E_ARG, "irf_get_depth: bad range");
     if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
     size_t n = end - start;

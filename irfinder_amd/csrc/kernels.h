@@ -16,7 +16,18 @@ namespace dev {
 constexpr int kJuncSpanBits = 28;
 constexpr int kJuncLeftShift = kJuncSpanBits + 1;
 constexpr uint64_t kJuncMaxGlobal = 1ull << 34;
-constexpr int kBucketShift = 9;     // 512-position buckets of the plane for the point / known-junction indices
+constexpr int kBucketShift = 9;     // 512-position buckets of the full coordinate space (point / junction indices, plane map)
+
+// Plane map.  Only the buckets that hold measured intron bases are kept in the difference planes (about a third of
+// GRCh38): pmap[b] = (index of the bucket among the kept ones << 1) | kept.  A position in a bucket that is not kept
+// maps to the start of the next kept bucket — the prefix sum at every kept position is unchanged by that, because the
+// map is monotone (an event still precedes exactly the kept positions it preceded before).
+__host__ __device__ inline uint64_t plane_coord(const uint32_t* pmap, uint64_t g) {
+    if (!pmap) return g;
+    const uint32_t m = pmap[g >> kBucketShift];
+    const uint64_t c = (uint64_t)(m >> 1) << kBucketShift;
+    return (m & 1u) ? c + (g & ((1u << kBucketShift) - 1u)) : c;
+}
 
 enum ErrBits : uint32_t {
     ERR_CHR_RANGE = 1u,        // frag_chr >= n_chr
@@ -35,7 +46,9 @@ struct CountTables {
     uint32_t sp_lo_add;        // candidates are the points in [bs + sp_lo_add, be - sp_hi_sub]
     uint32_t sp_hi_sub;
     uint32_t ablate;           // diagnostic only (IRF_ABLATE env): bit0 depth, 1 SpansPoint, 2 ROI, 3 junction, 4 chr
-    uint64_t plane_stride;     // elements per strand plane of the difference array
+    uint64_t plane_stride;     // elements per strand plane of the difference array (compact coordinates)
+    uint64_t full_size;        // size of the full coordinate space (chr_base + pos); junction keys, point / junction buckets
+    const uint32_t* pmap;      // full -> plane coordinates, one entry per 512-position bucket; nullptr = identity
     uint64_t junc_capacity;
     const uint64_t* chr_base;  // [n_chr]  offset of the chromosome inside a plane
     const uint32_t* chr_len;   // [n_chr]
@@ -141,7 +154,9 @@ struct IntronTables {
     const uint64_t* g_start;       // global start / end of the intron
     const uint64_t* g_end;
     const uint32_t* blk_off;       // [n_intron+1]
-    const uint64_t* blk_gstart;    // measured blocks, global coordinates
+    const uint64_t* blk_gstart;    // measured blocks, full coordinates
+    const uint64_t* blk_cstart;    // ... and their plane (compact) coordinates
+    const uint32_t* pmap;          // full -> plane map (nullptr = identity), for raw-coordinate flank windows
     const uint32_t* blk_len;
     const uint64_t* measured;      // [n_intron]
     const int32_t* sp_idx_start;   // index into sp_cnt of the point at Start (-1: none)

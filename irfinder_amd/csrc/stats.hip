@@ -46,7 +46,7 @@ struct Ctx {
     bool valid;
 };
 
-// Calls f(x, depth[x]) for every global position x in [gs, ge), spread over the whole workgroup.
+// Calls f(x, depth[x]) for every PLANE position x in [gs, ge), spread over the whole workgroup.
 // Every wave walks whole segments, so the shuffles inside always run with 64 active lanes.
 template <class F>
 __device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
@@ -196,14 +196,17 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                         const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
                         if (s < e) {
                             const uint32_t at = n;
-                            for_each_depth(C, s, e, [&](uint64_t x, uint32_t v) { s_win[at + (uint32_t)(x - s)] = v; });
+                            const uint64_t cs = T.blk_cstart[b] + (s - bs);      // plane coordinates
+                            for_each_depth(C, cs, cs + (e - s), [&](uint64_t x, uint32_t v) { s_win[at + (uint32_t)(x - cs)] = v; });
                             n += (uint32_t)(e - s);
                         }
                     }
                 } else {
-                    const uint64_t s = w0[wi], e = w1[wi];
-                    for_each_depth(C, s, e, [&](uint64_t x, uint32_t v) { s_win[(uint32_t)(x - s)] = v; });
-                    n = (uint32_t)(e - s);
+                    // raw coordinates: the engine keeps the buckets under the windows, contiguous in the plane
+                    const uint64_t e = w1[wi] - w0[wi];
+                    const uint64_t cs = C.valid ? plane_coord(T.pmap, w0[wi]) : w0[wi];
+                    for_each_depth(C, cs, cs + e, [&](uint64_t x, uint32_t v) { s_win[(uint32_t)(x - cs)] = v; });
+                    n = (uint32_t)e;
                 }
             }
             __syncthreads();
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         unsigned long long tsum = 0, nz = 0;
         bool ovf = false;
         for (uint32_t b = b0; b < b1; b++) {
-            const uint64_t bs = T.blk_gstart[b];
+            const uint64_t bs = T.blk_cstart[b];
             for_each_depth(C, bs, bs + T.blk_len[b], [&](uint64_t, uint32_t v) {
                 if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
                 vmax = v > vmax ? v : vmax;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                 for (int k = tid; k < kBins; k += kThreads) { s_cnt[k] = 0; s_sum[k] = 0; }
                 __syncthreads();
                 for (uint32_t b = b0; b < b1; b++) {
-                    const uint64_t bs = T.blk_gstart[b];
+                    const uint64_t bs = T.blk_cstart[b];
                     for_each_depth(C, bs, bs + T.blk_len[b], [&](uint64_t, uint32_t v) {
                         const bool in = lv == 0 || (shift + kBinBits >= 32 ? true : (v >> (shift + kBinBits)) == prefix);
                         if (in) {

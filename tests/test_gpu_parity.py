@@ -86,12 +86,24 @@ def test_order_and_batch_invariance_P1_P2():
 def test_nondir_is_pos_plus_neg_P4_and_junction_sums_P6():
     ann, sim = small_world(seed=9)
     names, lens, batch = read_batch(sim.bam(0, 15000))
-    e, g = run_gpu(ann.ref_texts(), names, lens, [batch])
+    e, g = run_gpu(ann.ref_texts(), names, lens, [batch], keep_depth=1)
     for c in range(len(names)):
         d0, d1, d2 = (e.depth(c, 0, lens[c], p) for p in (0, 1, 2))
         assert np.array_equal(d0 + d1, d2)
     assert g["chr_cnt"].sum() == batch.n_frag == g["n_fragments"]
     assert g["junc_cnt"].sum() == g["n_junction_events"]
+
+
+def test_full_and_compact_planes_agree():
+    """keep_depth=1 lays the planes out over the whole genome (FragmentsMap), the default keeps only the buckets with
+    measured intron bases; every result must be identical, and depth is only served in the first mode."""
+    ann, sim = small_world(seed=13, stranded=True)
+    names, lens, batch = read_batch(sim.bam(0, 20000))
+    e1, full = run_gpu(ann.ref_texts(), names, lens, split(batch, 2), keep_depth=1)
+    e0, compact = run_gpu(ann.ref_texts(), names, lens, split(batch, 3))
+    assert_results_equal(full, compact, rel=0.0, what="full vs compact planes")
+    with pytest.raises(engine.IrfError):
+        e0.depth(0, 0, 100, 2)
 
 
 def test_depth_matches_fragmentsmap():
