@@ -135,10 +135,15 @@ def main():
             eng.export_device(col, t.data_ptr())
         return t.view(*shape) if shape else t
 
+    phase = {"reset+submit": 0.0, "finalize": 0.0, "export+gather": 0.0, "d2h": 0.0}
+
     def step():
+        t_a = time.perf_counter()
         eng.reset()
         eng.submit(dbatch)
+        t_b = time.perf_counter()
         eng.finalize()
+        t_c = time.perf_counter()
         if world > 1:       # the strandedness vote is global: one all-reduce of two integers
             v = torch.tensor(eng.votes(), dtype=torch.int64, device=dev)
             eng.finalize_directional(irfdist.global_directionality(v, dist, eng.params.dir_ratio))
@@ -162,11 +167,19 @@ def main():
             got = irfdist.gather_tables(tabs, dist)
         else:
             got = irfdist.gather_tables(tabs, None)
-        if rank == 0:
-            out["ir_f64"] = got["ir_f64"].cpu()
-            out["ir_u32"] = got["ir_u32"].cpu()
-            out["n_junc"] = sum(int(k.numel()) for k in got["junc_keys"])
-            out["known_reads"] = int(got["known_cnt"].sum().item())
+        torch.cuda.synchronize()
+        t_d = time.perf_counter()
+        if rank == 0:       # the IR table lands in page-locked host memory
+            if "ir_f64" not in out:
+                out["ir_f64"] = torch.empty((8, n_in), dtype=torch.float64, pin_memory=True)
+                out["ir_u32"] = torch.empty((6, n_in), dtype=torch.int32, pin_memory=True)
+            out["ir_f64"].copy_(got["ir_f64"], non_blocking=True)
+            out["ir_u32"].copy_(got["ir_u32"], non_blocking=True)
+            torch.cuda.synchronize()
+            out["got"] = got
+        t_e = time.perf_counter()
+        phase["reset+submit"] += t_b - t_a; phase["finalize"] += t_c - t_b
+        phase["export+gather"] += t_d - t_c; phase["d2h"] += t_e - t_d
 
     def barrier():
         if world > 1:
@@ -176,6 +189,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    for k in phase:
+        phase[k] = 0.0
     t0 = time.perf_counter()
     kt = {"count_ms": 0.0, "scan_ms": 0.0, "stats_ms": 0.0, "junction_ms": 0.0}
     for _ in range(args.steps):
@@ -198,6 +213,8 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    out["n_junc"] = sum(int(k.numel()) for k in out["got"]["junc_keys"])
+    out["known_reads"] = int(out["got"]["known_cnt"].to(torch.int64).sum().item())
 
     # ---------------- roofline of the dominant kernel (algorithmic bytes: SURVEY §8 d / DESIGN.md) ----------------
     G = sum(((l + 1 + 63) // 64) * 64 for l, o in zip(lens, owned) if o)
@@ -292,6 +309,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    line["host_phases_ms"] = {k: round(v / max(args.steps, 1) * 1e3, 3) for k, v in phase.items()}
     line.update(extra)
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -14,12 +14,16 @@
 // The integers that come out are identical to what the map walk yields; the
 // few fp64 operations (divisions, one interpolation) are done in the same order
 // as the CPU restatement, with contraction off, so doubles match bit for bit.
+//
 // Depth is never materialised: the workgroup rebuilds it on the fly from the
 // difference planes.  finalize() leaves, for every 256-position segment of a
 // plane, the depth just before the segment ("carry", scan.hip); a wave loads a
 // segment as 64 x int4, one wave-wide prefix sum gives the 256 depths.  Both
 // strands (non-directional table) are summed BEFORE the prefix (it is linear).
-// HBM-bound: 4 B (one strand) or 8 B (both) per measured base, read once.
+// HBM-bound: 4 B (one strand) or 8 B (both) per measured base, read once; the
+// first/last-50-nt windows are captured from the same pass.  Two segments are in
+// flight per wave, and the histogram update is aggregated per wave (depth is
+// piecewise constant, so most of a segment's 256 values are equal).
 #include "kernels.h"
 
 namespace irf {
@@ -34,7 +38,6 @@ constexpr int kBins = 1 << kBinBits;
 constexpr int kBinsPerThread = kBins / kThreads;   // 8
 constexpr int kMaxFlank = 1024;
 constexpr int kQueries = 8;
-
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 
 struct Ctx {
@@ -43,49 +46,61 @@ struct Ctx {
     const uint32_t* c0;             // carries, one per 256-position segment
     const uint32_t* c1;
     int plane;                      // 0,1: one strand; 2: both
-    bool valid;
 };
 
-// Calls f(x, depth[x]) for every PLANE position x in [gs, ge), spread over the whole workgroup.
-// Every wave walks whole segments, so the shuffles inside always run with 64 active lanes.
+struct Seg { int4 a; uint32_t carry; };
+
+__device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane) {
+    Seg s;
+    const uint64_t e0 = k * kSeg + lane * 4u;
+    if (C.plane == 2) {
+        const int4 u = *reinterpret_cast<const int4*>(C.d0 + e0);
+        const int4 v = *reinterpret_cast<const int4*>(C.d1 + e0);
+        s.a.x = u.x + v.x; s.a.y = u.y + v.y; s.a.z = u.z + v.z; s.a.w = u.w + v.w;
+        s.carry = C.c0[k] + C.c1[k];
+    } else if (C.plane == 1) {
+        s.a = *reinterpret_cast<const int4*>(C.d1 + e0);
+        s.carry = C.c1[k];
+    } else {
+        s.a = *reinterpret_cast<const int4*>(C.d0 + e0);
+        s.carry = C.c0[k];
+    }
+    return s;
+}
+
+// f(x, v, valid) is called by ALL 64 lanes (wave-uniformly) four times per segment; valid = x in [gs, ge).
+template <class F>
+__device__ __forceinline__ void emit_seg(const Seg& s, uint64_t k, uint32_t lane, uint64_t gs, uint64_t ge, F&& f) {
+    const uint32_t t = (uint32_t)(s.a.x + s.a.y + s.a.z + s.a.w);
+    uint32_t incl = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += o;
+    }
+    const uint64_t e0 = k * kSeg + lane * 4u;
+    const uint32_t v0 = s.carry + incl - t + (uint32_t)s.a.x;
+    const uint32_t v1 = v0 + (uint32_t)s.a.y, v2 = v1 + (uint32_t)s.a.z, v3 = v2 + (uint32_t)s.a.w;
+    f(e0 + 0, v0, e0 + 0 >= gs && e0 + 0 < ge);
+    f(e0 + 1, v1, e0 + 1 >= gs && e0 + 1 < ge);
+    f(e0 + 2, v2, e0 + 2 >= gs && e0 + 2 < ge);
+    f(e0 + 3, v3, e0 + 3 >= gs && e0 + 3 < ge);
+}
+
+// Depth of every PLANE position in [gs, ge), spread over the workgroup: each wave walks whole 256-position
+// segments (so every shuffle / ballot inside f runs with 64 active lanes), two segments in flight.
 template <class F>
 __device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
     if (gs >= ge) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (!C.valid) {                 // chromosome absent from the BAM header / not owned: depth 0 everywhere
-        for (uint64_t x = gs + threadIdx.x; x < ge; x += kThreads) f(x, 0u);
-        return;
-    }
     const uint64_t k0 = gs / kSeg, k1 = (ge - 1) / kSeg;
-    for (uint64_t k = k0 + wave; k <= k1; k += kWaves) {
-        const uint64_t e0 = k * kSeg + lane * 4u;
-        int4 a;
-        uint32_t carry;
-        if (C.plane == 2) {
-            const int4 u = *reinterpret_cast<const int4*>(C.d0 + e0);
-            const int4 v = *reinterpret_cast<const int4*>(C.d1 + e0);
-            a.x = u.x + v.x; a.y = u.y + v.y; a.z = u.z + v.z; a.w = u.w + v.w;
-            carry = C.c0[k] + C.c1[k];
-        } else if (C.plane == 1) {
-            a = *reinterpret_cast<const int4*>(C.d1 + e0);
-            carry = C.c1[k];
-        } else {
-            a = *reinterpret_cast<const int4*>(C.d0 + e0);
-            carry = C.c0[k];
-        }
-        const uint32_t t = (uint32_t)(a.x + a.y + a.z + a.w);
-        uint32_t incl = t;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += o;
-        }
-        const uint32_t v0 = carry + incl - t + (uint32_t)a.x;
-        const uint32_t v1 = v0 + (uint32_t)a.y, v2 = v1 + (uint32_t)a.z, v3 = v2 + (uint32_t)a.w;
-        if (e0 + 0 >= gs && e0 + 0 < ge) f(e0 + 0, v0);
-        if (e0 + 1 >= gs && e0 + 1 < ge) f(e0 + 1, v1);
-        if (e0 + 2 >= gs && e0 + 2 < ge) f(e0 + 2, v2);
-        if (e0 + 3 >= gs && e0 + 3 < ge) f(e0 + 3, v3);
+    for (uint64_t k = k0 + wave; k <= k1; k += 2 * kWaves) {
+        const bool two = k + kWaves <= k1;                 // wave-uniform
+        const Seg sa = load_seg(C, k, lane);
+        Seg sb = sa;
+        if (two) sb = load_seg(C, k + kWaves, lane);
+        emit_seg(sa, k, lane, gs, ge, f);
+        if (two) emit_seg(sb, k + kWaves, lane, gs, ge, f);
     }
 }
 
@@ -113,61 +128,42 @@ __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long
     __syncthreads();
 }
 
-// rank-by-counting sort of n (<= kMaxFlank) LDS values, then the p-th percentile (OQ-7 formula)
-__device__ double window_percentile(const uint32_t* s_win, uint32_t* s_sorted, uint32_t n, uint32_t pct, bool interpolate,
-                                    double* s_out) {
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
-        const uint32_t v = s_win[i];
-        uint32_t r = 0;
-        for (uint32_t j = 0; j < n; j++) {
-            const uint32_t w = s_win[j];
-            r += (w < v || (w == v && j < i)) ? 1u : 0u;
-        }
-        s_sorted[r] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double res = 0.0;
-        if (n > 0) {
-            const unsigned long long num = (unsigned long long)(n + 1u) * pct;
-            const unsigned long long k = num / 100ull;
-            const uint32_t rem = (uint32_t)(num % 100ull);
-            if (k < 1) res = (double)s_sorted[0];
-            else if (k >= n) res = (double)s_sorted[n - 1];
-            else {
-                const double vk = (double)s_sorted[k - 1];
-                if (!interpolate || rem == 0) res = vk;
-                else res = vk + ((double)rem / 100.0) * ((double)s_sorted[k] - vk);
-            }
-        }
-        *s_out = res;
-    }
-    __syncthreads();
-    return *s_out;
+// p-th percentile (OQ-7 formula) of n sorted values
+__device__ __forceinline__ double percentile_sorted(const uint32_t* sorted, uint32_t n, uint32_t pct, bool interpolate) {
+    if (n == 0) return 0.0;
+    const unsigned long long num = (unsigned long long)(n + 1u) * pct;
+    const unsigned long long k = num / 100ull;
+    const uint32_t rem = (uint32_t)(num % 100ull);
+    if (k < 1) return (double)sorted[0];
+    if (k >= n) return (double)sorted[n - 1];
+    const double vk = (double)sorted[k - 1];
+    if (!interpolate || rem == 0) return vk;
+    return vk + ((double)rem / 100.0) * ((double)sorted[k] - vk);
 }
 
 __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) {
     __shared__ uint32_t s_cnt[kBins];
-    __shared__ unsigned long long s_sum[kBins];            // multi-level sums; doubles as the flank-window buffers
+    __shared__ unsigned long long s_sum[kBins];            // multi-level sums; first doubles as the flank-window buffers
     __shared__ uint32_t s_wc[kWaves];
     __shared__ unsigned long long s_ws[kWaves];
     __shared__ uint32_t s_max, s_overflow, s_sel_bin, s_sel_cnt;
     __shared__ unsigned long long s_total, s_nz, s_sel_sum;
     __shared__ uint32_t s_qval[kQueries];
     __shared__ unsigned long long s_qsum[kQueries];
-    __shared__ double s_dbl;
     __shared__ unsigned long long s_qrank[kQueries];
     __shared__ uint32_t s_qneed[kQueries];
     __shared__ uint32_t s_prem[3];
+    __shared__ double s_flank[2];
 
     const uint32_t i = blockIdx.x;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
     Ctx C;
     C.d0 = T.diff;
     C.d1 = T.diff + T.plane_stride;
     C.c0 = T.carry;
     C.c1 = T.carry + T.plane_stride / kSeg;
-    C.valid = T.valid[i] != 0;
+    const bool valid = T.valid[i] != 0;     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
     C.plane = 2;
     if (T.directionality != 0) C.plane = ((T.strand_plus[i] != 0) == (T.directionality > 0)) ? 1 : 0;
 
@@ -175,61 +171,79 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     const unsigned long long N = T.measured[i];
     const uint64_t gS = T.g_start[i], gE = T.g_end[i];
 
-    // ---------------- flank windows (first / last flank_len nt, median) ----------------
-    double flank[2] = {0.0, 0.0};
+    // window buffers live in the (not yet used) sum array: win[0], win[1], sorted[0], sorted[1]
+    uint32_t* s_win0 = reinterpret_cast<uint32_t*>(s_sum);
+    uint32_t* s_win1 = s_win0 + kMaxFlank;
+    uint32_t* s_sorted0 = s_win1 + kMaxFlank;
+    uint32_t* s_sorted1 = s_sorted0 + kMaxFlank;
+
+    // first / last flank_len nt of the intron, flank_offset nt inside it (full coordinates)
+    uint64_t w0[2], w1[2];
     {
-        uint32_t* s_win = reinterpret_cast<uint32_t*>(s_sum);
-        uint32_t* s_sorted = s_win + kMaxFlank;
         const uint64_t ilen = gE - gS;
         const uint64_t fo = T.flank_offset, fl = T.flank_len;
-        uint64_t w0[2], w1[2];
         w0[0] = gS + (fo < ilen ? fo : ilen);
         w1[0] = gS + (fo + fl < ilen ? fo + fl : ilen);
         w1[1] = gE - (fo < ilen ? fo : ilen);
         w0[1] = gE - (fo + fl < ilen ? fo + fl : ilen);
-        for (int wi = 0; wi < 2; wi++) {
-            uint32_t n = 0;
-            if (w0[wi] < w1[wi]) {
-                if (T.flank_use_measured) {
-                    for (uint32_t b = b0; b < b1; b++) {
-                        const uint64_t bs = T.blk_gstart[b], be = bs + T.blk_len[b];
-                        const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
-                        if (s < e) {
-                            const uint32_t at = n;
-                            const uint64_t cs = T.blk_cstart[b] + (s - bs);      // plane coordinates
-                            for_each_depth(C, cs, cs + (e - s), [&](uint64_t x, uint32_t v) { s_win[at + (uint32_t)(x - cs)] = v; });
-                            n += (uint32_t)(e - s);
-                        }
-                    }
-                } else {
-                    // raw coordinates: the engine keeps the buckets under the windows, contiguous in the plane
-                    const uint64_t e = w1[wi] - w0[wi];
-                    const uint64_t cs = C.valid ? plane_coord(T.pmap, w0[wi]) : w0[wi];
-                    for_each_depth(C, cs, cs + e, [&](uint64_t x, uint32_t v) { s_win[(uint32_t)(x - cs)] = v; });
-                    n = (uint32_t)e;
-                }
-            }
-            __syncthreads();
-            flank[wi] = window_percentile(s_win, s_sorted, n, 50u, T.pct_interpolate != 0, &s_dbl);
-            __syncthreads();
-        }
     }
 
-    // ---------------- pass A: histogram (clipped), max, total, non-zero ----------------
     for (int k = tid; k < kBins; k += kThreads) s_cnt[k] = 0;
     if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; }
     __syncthreads();
-    {
+
+    // ---------------- pass A: histogram (clipped), max, total, non-zero, window capture ----------------
+    uint32_t nwin[2] = {0, 0};
+    if (valid) {
         uint32_t vmax = 0;
         unsigned long long tsum = 0, nz = 0;
         bool ovf = false;
+        if (!T.flank_use_measured) {
+            // raw-coordinate windows: the engine keeps the buckets under them, contiguous in the plane
+            for (int wi = 0; wi < 2; wi++) {
+                if (w0[wi] >= w1[wi]) continue;
+                const uint64_t len = w1[wi] - w0[wi];
+                const uint64_t cs = plane_coord(T.pmap, w0[wi]);
+                uint32_t* dst = wi ? s_win1 : s_win0;
+                for_each_depth(C, cs, cs + len, [&](uint64_t x, uint32_t v, bool ok) { if (ok) dst[(uint32_t)(x - cs)] = v; });
+                nwin[wi] = (uint32_t)len;
+            }
+        }
         for (uint32_t b = b0; b < b1; b++) {
-            const uint64_t bs = T.blk_cstart[b];
-            for_each_depth(C, bs, bs + T.blk_len[b], [&](uint64_t, uint32_t v) {
-                if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
-                vmax = v > vmax ? v : vmax;
-                tsum += v;
-                nz += v ? 1u : 0u;
+            const uint64_t bs = T.blk_gstart[b], bc = T.blk_cstart[b];
+            const uint64_t bl = T.blk_len[b];
+            // the parts of the two windows inside this block, in plane coordinates (wave-uniform)
+            uint64_t ws[2] = {0, 0}, we[2] = {0, 0};
+            const uint32_t at0 = nwin[0], at1 = nwin[1];
+            if (T.flank_use_measured) {
+#pragma unroll
+                for (int wi = 0; wi < 2; wi++) {
+                    const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = bs + bl < w1[wi] ? bs + bl : w1[wi];
+                    if (s < e) { ws[wi] = bc + (s - bs); we[wi] = bc + (e - bs); nwin[wi] += (uint32_t)(e - s); }
+                }
+            }
+            const uint64_t ws0 = ws[0], we0 = we[0], ws1 = ws[1], we1 = we[1];
+            for_each_depth(C, bc, bc + bl, [&](uint64_t x, uint32_t v, bool ok) {
+                // wave-aggregated histogram update: lanes that share the first valid lane's value add once
+                const uint64_t act = __ballot(ok);
+                if (act) {
+                    const uint32_t first = __shfl(v, __ffsll((long long)act) - 1);
+                    const uint64_t same = __ballot(ok && v == first);
+                    if (ok) {
+                        if (v == first) {
+                            if (lane == (uint32_t)(__ffsll((long long)same) - 1)) {
+                                if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], (uint32_t)__popcll(same)); else ovf = true;
+                            }
+                        } else {
+                            if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
+                        }
+                        vmax = v > vmax ? v : vmax;
+                        tsum += v;
+                        nz += v ? 1u : 0u;
+                        if (x >= ws0 && x < we0) s_win0[at0 + (uint32_t)(x - ws0)] = v;
+                        if (x >= ws1 && x < we1) s_win1[at1 + (uint32_t)(x - ws1)] = v;
+                    }
+                }
             });
         }
 #pragma unroll
@@ -239,16 +253,55 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
             tsum += __shfl_xor(tsum, d);
             nz += __shfl_xor(nz, d);
         }
-        if ((tid & 63u) == 0) {
+        if (lane == 0) {
             atomicMax(&s_max, vmax);
             atomicAdd(&s_total, tsum);
             atomicAdd(&s_nz, nz);
         }
         if (ovf) s_overflow = 1;
+    } else {
+        // all-zero depth: N zeros in the histogram, all-zero windows of the right size
+        if (tid == 0) s_cnt[0] = (uint32_t)N;
+        for (int wi = 0; wi < 2; wi++) {
+            uint32_t n = 0;
+            if (w0[wi] < w1[wi]) {
+                if (T.flank_use_measured) {
+                    for (uint32_t b = b0; b < b1; b++) {
+                        const uint64_t bs = T.blk_gstart[b], be = bs + T.blk_len[b];
+                        const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
+                        if (s < e) n += (uint32_t)(e - s);
+                    }
+                } else {
+                    n = (uint32_t)(w1[wi] - w0[wi]);
+                }
+            }
+            uint32_t* dst = wi ? s_win1 : s_win0;
+            for (uint32_t k = tid; k < n; k += kThreads) dst[k] = 0;
+            nwin[wi] = n;
+        }
     }
     __syncthreads();
     const uint32_t vmax = s_max;
     const unsigned long long total = s_total, nzc = s_nz;
+    const bool overflow = s_overflow != 0;
+
+    // ---------------- flank medians: rank-by-counting sort of both windows ----------------
+    {
+        const uint32_t n0 = nwin[0], n1 = nwin[1];
+        for (uint32_t e = tid; e < n0 + n1; e += kThreads) {
+            const bool second = e >= n0;
+            const uint32_t* w = second ? s_win1 : s_win0;
+            uint32_t* so = second ? s_sorted1 : s_sorted0;
+            const uint32_t n = second ? n1 : n0, idx = second ? e - n0 : e;
+            const uint32_t v = w[idx];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t o = w[j];
+                r += (o < v || (o == v && j < idx)) ? 1u : 0u;
+            }
+            so[r] = v;
+        }
+    }
 
     // ---------------- the rank queries ----------------
     // q0,q1: sums below ranks lo / hi of the trimmed mean; q2..q7: values for p25, p50, p75 (ranks k-1 and k)
@@ -276,8 +329,11 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     }
     if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
     __syncthreads();
+    if (tid < 2) {      // window medians (the sorted windows are complete after the barrier above)
+        s_flank[tid] = percentile_sorted(tid ? s_sorted1 : s_sorted0, nwin[tid], 50u, T.pct_interpolate != 0);
+    }
 
-    if (N > 0 && !s_overflow) {
+    if (N > 0 && !overflow) {
         // single level: bins are the depths themselves
         uint32_t c[kBinsPerThread];
         uint32_t tot = 0;
@@ -308,7 +364,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
         __syncthreads();
     } else if (N > 0) {
-        // multi-level radix select, one descent per query
+        // multi-level radix select, one descent per query (the window buffers are dead by now: s_flank holds the medians)
+        __syncthreads();
         int bits = 32 - __clz((int)vmax);
         int levels = (bits + kBinBits - 1) / kBinBits;
         if (levels < 1) levels = 1;
@@ -322,9 +379,9 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                 for (int k = tid; k < kBins; k += kThreads) { s_cnt[k] = 0; s_sum[k] = 0; }
                 __syncthreads();
                 for (uint32_t b = b0; b < b1; b++) {
-                    const uint64_t bs = T.blk_cstart[b];
-                    for_each_depth(C, bs, bs + T.blk_len[b], [&](uint64_t, uint32_t v) {
-                        const bool in = lv == 0 || (shift + kBinBits >= 32 ? true : (v >> (shift + kBinBits)) == prefix);
+                    const uint64_t bc = T.blk_cstart[b];
+                    for_each_depth(C, bc, bc + T.blk_len[b], [&](uint64_t, uint32_t v, bool ok) {
+                        const bool in = ok && (lv == 0 || (v >> (shift + kBinBits)) == prefix);
                         if (in) {
                             const uint32_t bin = (v >> shift) & (uint32_t)(kBins - 1);
                             atomicAdd(&s_cnt[bin], 1u);
@@ -365,10 +422,13 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
             if (tid == 0) { s_qval[q] = prefix; s_qsum[q] = sum_below + (unsigned long long)prefix * r; }
         }
         __syncthreads();
+    } else {
+        __syncthreads();
     }
 
     // ---------------- the row ----------------
     if (tid == 0) {
+        const double flank0 = s_flank[0], flank1 = s_flank[1];
         double coverage = 0.0, depth = 0.0, pv[3] = {0.0, 0.0, 0.0};
         if (N > 0) {
             coverage = (double)nzc / (double)N;
@@ -384,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
         const int plane = C.plane;
         uint32_t spl = 0, spr = 0, jl = 0, jr = 0, je = 0;
-        if (C.valid) {
+        if (valid) {
             const int32_t a = T.sp_idx_start[i], b = T.sp_idx_end[i];
             if (a >= 0) spl = plane == 2 ? T.sp_cnt[a] + T.sp_cnt[(uint64_t)T.n_sp + a] : T.sp_cnt[(uint64_t)plane * T.n_sp + a];
             if (b >= 0) spr = plane == 2 ? T.sp_cnt[b] + T.sp_cnt[(uint64_t)T.n_sp + b] : T.sp_cnt[(uint64_t)plane * T.n_sp + b];
@@ -412,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         const double den = depth + (double)smax;
         const double irratio = den > 0.0 ? depth / den : 0.0;
         const double sp_max = (double)(spl > spr ? spl : spr);
-        const double fl_max = flank[0] > flank[1] ? flank[0] : flank[1];
+        const double fl_max = flank0 > flank1 ? flank0 : flank1;
         const double maxflank = sp_max > fl_max ? sp_max : fl_max;
         uint32_t warn;
         if ((double)je + depth < T.warn_lowcover_min) warn = 1;
@@ -426,8 +486,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         T.out_f64[2 * n + i] = pv[0];
         T.out_f64[3 * n + i] = pv[1];
         T.out_f64[4 * n + i] = pv[2];
-        T.out_f64[5 * n + i] = flank[0];
-        T.out_f64[6 * n + i] = flank[1];
+        T.out_f64[5 * n + i] = flank0;
+        T.out_f64[6 * n + i] = flank1;
         T.out_f64[7 * n + i] = irratio;
         T.out_u32[0 * n + i] = spl;
         T.out_u32[1 * n + i] = spr;
