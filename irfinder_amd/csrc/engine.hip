@@ -635,6 +635,7 @@ void irf_ctx::launch_stats(int t, int dirn) {
     T.n_ustart = n_us; T.n_uend = n_ue;
     T.ukeys = d_ukeys.p; T.ucount = d_ucount.p; T.n_unique = n_unique;
     T.kj_idx = d_kj_idx.p; T.known_cnt = d_known_cnt.p; T.n_kj = n_kj;
+    { const char* ab = getenv("IRF_ABLATE_STATS"); T.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
     T.trim_centre_pct = P.trim_centre_pct; T.pct_interpolate = P.pct_interpolate;
     T.flank_offset = P.flank_offset; T.flank_len = P.flank_len; T.flank_use_measured = P.flank_use_measured;
     T.directionality = dirn;

@@ -173,7 +173,7 @@ struct IntronTables {
     const int32_t* kj_idx;         // [n_intron] row of the known-junction table for (Start,End), -1 if not in ref-sj
     const uint32_t* known_cnt;     // [2][n_kj]
     uint32_t n_kj;
-    uint32_t pad1;
+    uint32_t ablate;               // diagnostic only (IRF_ABLATE_STATS): bit0 no depth pass, bit1 no row tail
     // parameters
     uint32_t trim_centre_pct, pct_interpolate, flank_offset, flank_len, flank_use_measured;
     int32_t directionality;        // 0: non-directional table (both planes)

@@ -22,8 +22,9 @@
 // strands (non-directional table) are summed BEFORE the prefix (it is linear).
 // HBM-bound: 4 B (one strand) or 8 B (both) per measured base, read once; the
 // first/last-50-nt windows are captured from the same pass.  Two segments are in
-// flight per wave, and the histogram update is aggregated per wave (depth is
-// piecewise constant, so most of a segment's 256 values are equal).
+// flight per wave; depth is piecewise constant, so a segment that holds one
+// value 256 times (most do) costs ONE LDS atomic, and mixed segments aggregate
+// equal values per wave before touching the histogram.
 #include "kernels.h"
 
 namespace irf {
@@ -50,6 +51,18 @@ struct Ctx {
 
 struct Seg { int4 a; uint32_t carry; };
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (6 VALU ops, no LDS traffic).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return (uint32_t)v;
+}
+
 __device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane) {
     Seg s;
     const uint64_t e0 = k * kSeg + lane * 4u;
@@ -68,29 +81,22 @@ __device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane)
     return s;
 }
 
-// f(x, v, valid) is called by ALL 64 lanes (wave-uniformly) four times per segment; valid = x in [gs, ge).
+// One segment: f(seg0, e0, v0, v1, v2, v3) is called by ALL 64 lanes; seg0 = first plane position of the segment,
+// e0 = this lane's first position, v0..v3 = depth at e0..e0+3.
 template <class F>
-__device__ __forceinline__ void emit_seg(const Seg& s, uint64_t k, uint32_t lane, uint64_t gs, uint64_t ge, F&& f) {
+__device__ __forceinline__ void emit_seg(const Seg& s, uint64_t k, uint32_t lane, F&& f) {
     const uint32_t t = (uint32_t)(s.a.x + s.a.y + s.a.z + s.a.w);
-    uint32_t incl = t;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if ((int)lane >= d) incl += o;
-    }
-    const uint64_t e0 = k * kSeg + lane * 4u;
+    const uint32_t incl = wave_inclusive_scan_dpp(t);
     const uint32_t v0 = s.carry + incl - t + (uint32_t)s.a.x;
     const uint32_t v1 = v0 + (uint32_t)s.a.y, v2 = v1 + (uint32_t)s.a.z, v3 = v2 + (uint32_t)s.a.w;
-    f(e0 + 0, v0, e0 + 0 >= gs && e0 + 0 < ge);
-    f(e0 + 1, v1, e0 + 1 >= gs && e0 + 1 < ge);
-    f(e0 + 2, v2, e0 + 2 >= gs && e0 + 2 < ge);
-    f(e0 + 3, v3, e0 + 3 >= gs && e0 + 3 < ge);
+    f(k * kSeg, k * kSeg + lane * 4u, v0, v1, v2, v3);
 }
 
-// Depth of every PLANE position in [gs, ge), spread over the workgroup: each wave walks whole 256-position
-// segments (so every shuffle / ballot inside f runs with 64 active lanes), two segments in flight.
+// Depth of the PLANE positions of every 256-position segment that overlaps [gs, ge), spread over the workgroup: each
+// wave walks whole segments (so every DPP / ballot inside f runs with 64 active lanes), two segments in flight.
+// The callback clips to [gs, ge) itself.
 template <class F>
-__device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
+__device__ __forceinline__ void for_each_segment(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
     if (gs >= ge) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t k0 = gs / kSeg, k1 = (ge - 1) / kSeg;
@@ -99,9 +105,20 @@ __device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64
         const Seg sa = load_seg(C, k, lane);
         Seg sb = sa;
         if (two) sb = load_seg(C, k + kWaves, lane);
-        emit_seg(sa, k, lane, gs, ge, f);
-        if (two) emit_seg(sb, k + kWaves, lane, gs, ge, f);
+        emit_seg(sa, k, lane, f);
+        if (two) emit_seg(sb, k + kWaves, lane, f);
     }
+}
+
+// per-position form: f(x, v, ok) for the four positions of every lane, ok = x in [gs, ge)
+template <class F>
+__device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
+    for_each_segment(C, gs, ge, [&](uint64_t, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+        f(e0 + 0, v0, e0 + 0 >= gs && e0 + 0 < ge);
+        f(e0 + 1, v1, e0 + 1 >= gs && e0 + 1 < ge);
+        f(e0 + 2, v2, e0 + 2 >= gs && e0 + 2 < ge);
+        f(e0 + 3, v3, e0 + 3 >= gs && e0 + 3 < ge);
+    });
 }
 
 // Exclusive prefix over the 256 threads of (count, sum); s_w* are LDS scratch of kWaves entries.
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     C.d1 = T.diff + T.plane_stride;
     C.c0 = T.carry;
     C.c1 = T.carry + T.plane_stride / kSeg;
-    const bool valid = T.valid[i] != 0;     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
+    const bool valid = T.valid[i] != 0 && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
     C.plane = 2;
     if (T.directionality != 0) C.plane = ((T.strand_plus[i] != 0) == (T.directionality > 0)) ? 1 : 0;
 
@@ -192,11 +209,10 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; }
     __syncthreads();
 
-    // ---------------- pass A: histogram (clipped), max, total, non-zero, window capture ----------------
+    // ---------------- pass A: histogram (clipped) + window capture ----------------
+    // (total, non-zero count and maximum are read off the histogram afterwards)
     uint32_t nwin[2] = {0, 0};
     if (valid) {
-        uint32_t vmax = 0;
-        unsigned long long tsum = 0, nz = 0;
         bool ovf = false;
         if (!T.flank_use_measured) {
             // raw-coordinate windows: the engine keeps the buckets under them, contiguous in the plane
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
         for (uint32_t b = b0; b < b1; b++) {
             const uint64_t bs = T.blk_gstart[b], bc = T.blk_cstart[b];
-            const uint64_t bl = T.blk_len[b];
+            const uint64_t bl = T.blk_len[b], be_c = bc + bl;
             // the parts of the two windows inside this block, in plane coordinates (wave-uniform)
             uint64_t ws[2] = {0, 0}, we[2] = {0, 0};
             const uint32_t at0 = nwin[0], at1 = nwin[1];
@@ -223,40 +239,40 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                 }
             }
             const uint64_t ws0 = ws[0], we0 = we[0], ws1 = ws[1], we1 = we[1];
-            for_each_depth(C, bc, bc + bl, [&](uint64_t x, uint32_t v, bool ok) {
-                // wave-aggregated histogram update: lanes that share the first valid lane's value add once
-                const uint64_t act = __ballot(ok);
-                if (act) {
-                    const uint32_t first = __shfl(v, __ffsll((long long)act) - 1);
-                    const uint64_t same = __ballot(ok && v == first);
+            for_each_segment(C, bc, be_c, [&](uint64_t seg0, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
+                const bool inner = seg0 >= bc && seg0 + kSeg <= be_c &&                         // whole segment measured
+                                   !(seg0 < we0 && seg0 + kSeg > ws0) && !(seg0 < we1 && seg0 + kSeg > ws1);
+                const bool flat = v0 == first && v1 == first && v2 == first && v3 == first;
+                if (inner && __ballot(flat) == ~0ull) {
+                    // depth is piecewise constant: most segments hold one value 256 times -> one LDS atomic
+                    if (lane == 0) { if (first < (uint32_t)kBins) atomicAdd(&s_cnt[first], (uint32_t)kSeg); else ovf = true; }
+                    return;
+                }
+                const uint32_t vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint64_t x = e0 + j;
+                    const uint32_t v = vv[j];
+                    const bool ok = x >= bc && x < be_c;
+                    // wave-aggregated histogram update: lanes that share the first valid lane's value add once
+                    const uint64_t act = __ballot(ok);
+                    if (!act) continue;
+                    const uint32_t lead = __shfl(v, __ffsll((long long)act) - 1);
+                    const uint64_t same = __ballot(ok && v == lead);
                     if (ok) {
-                        if (v == first) {
+                        if (v == lead) {
                             if (lane == (uint32_t)(__ffsll((long long)same) - 1)) {
                                 if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], (uint32_t)__popcll(same)); else ovf = true;
                             }
                         } else {
                             if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
                         }
-                        vmax = v > vmax ? v : vmax;
-                        tsum += v;
-                        nz += v ? 1u : 0u;
                         if (x >= ws0 && x < we0) s_win0[at0 + (uint32_t)(x - ws0)] = v;
                         if (x >= ws1 && x < we1) s_win1[at1 + (uint32_t)(x - ws1)] = v;
                     }
                 }
             });
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            uint32_t om = __shfl_xor(vmax, d);
-            vmax = om > vmax ? om : vmax;
-            tsum += __shfl_xor(tsum, d);
-            nz += __shfl_xor(nz, d);
-        }
-        if (lane == 0) {
-            atomicMax(&s_max, vmax);
-            atomicAdd(&s_total, tsum);
-            atomicAdd(&s_nz, nz);
         }
         if (ovf) s_overflow = 1;
     } else {
@@ -281,9 +297,28 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
     }
     __syncthreads();
-    const uint32_t vmax = s_max;
-    const unsigned long long total = s_total, nzc = s_nz;
     const bool overflow = s_overflow != 0;
+    if (overflow) {
+        // depth beyond the single-level histogram somewhere: maximum, total and non-zero count by a pass of their own
+        uint32_t vmax = 0;
+        unsigned long long tsum = 0, nz = 0;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint64_t bc = T.blk_cstart[b];
+            for_each_depth(C, bc, bc + T.blk_len[b], [&](uint64_t, uint32_t v, bool ok) {
+                if (ok) { vmax = v > vmax ? v : vmax; tsum += v; nz += v ? 1u : 0u; }
+            });
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            uint32_t om = __shfl_xor(vmax, d);
+            vmax = om > vmax ? om : vmax;
+            tsum += __shfl_xor(tsum, d);
+            nz += __shfl_xor(nz, d);
+        }
+        if (lane == 0) { atomicMax(&s_max, vmax); atomicAdd(&s_total, tsum); atomicAdd(&s_nz, nz); }
+    } else if (tid == 0) {
+        s_nz = N - s_cnt[0];
+    }
 
     // ---------------- flank medians: rank-by-counting sort of both windows ----------------
     {
@@ -347,6 +382,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         uint32_t pre;
         unsigned long long pre_sum;
         block_excl_scan(tot, tsum, pre, pre_sum, s_wc, s_ws);
+        if (tid == kThreads - 1) s_total = pre_sum + tsum;       // sum of all depths
 #pragma unroll
         for (int q = 0; q < kQueries; q++) {
             if (!s_qneed[q]) continue;
@@ -366,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     } else if (N > 0) {
         // multi-level radix select, one descent per query (the window buffers are dead by now: s_flank holds the medians)
         __syncthreads();
-        int bits = 32 - __clz((int)vmax);
+        int bits = 32 - __clz((int)s_max);
         int levels = (bits + kBinBits - 1) / kBinBits;
         if (levels < 1) levels = 1;
         for (int q = 0; q < kQueries; q++) {
@@ -429,6 +465,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     // ---------------- the row ----------------
     if (tid == 0) {
         const double flank0 = s_flank[0], flank1 = s_flank[1];
+        const unsigned long long total = s_total, nzc = s_nz;
         double coverage = 0.0, depth = 0.0, pv[3] = {0.0, 0.0, 0.0};
         if (N > 0) {
             coverage = (double)nzc / (double)N;
@@ -444,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
         const int plane = C.plane;
         uint32_t spl = 0, spr = 0, jl = 0, jr = 0, je = 0;
-        if (valid) {
+        if (valid && !(T.ablate & 2u)) {
             const int32_t a = T.sp_idx_start[i], b = T.sp_idx_end[i];
             if (a >= 0) spl = plane == 2 ? T.sp_cnt[a] + T.sp_cnt[(uint64_t)T.n_sp + a] : T.sp_cnt[(uint64_t)plane * T.n_sp + a];
             if (b >= 0) spr = plane == 2 ? T.sp_cnt[b] + T.sp_cnt[(uint64_t)T.n_sp + b] : T.sp_cnt[(uint64_t)plane * T.n_sp + b];
