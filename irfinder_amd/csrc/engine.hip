@@ -930,7 +930,7 @@ int irf_create(const irf_params* params, const irf_ref* ref, int device, irf_ctx
     } else {
         irf_params_default(&P);
     }
-    if (P.flank_len > 1024 || P.trim_centre_pct > 100) return IRF_E_ARG;
+    if (P.flank_len > 512 || P.trim_centre_pct > 100) return IRF_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return IRF_E_DEVICE;
     irf_ctx* c = new irf_ctx();

@@ -34,10 +34,10 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kBinBits = 11;
+constexpr int kBinBits = 10;
 constexpr int kBins = 1 << kBinBits;
 constexpr int kBinsPerThread = kBins / kThreads;   // 8
-constexpr int kMaxFlank = 1024;
+constexpr int kMaxFlank = 512;
 constexpr int kQueries = 8;
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 

@@ -24,7 +24,7 @@ db = engine.device_batch(dten, host.n_frag, host.n_blk)
 ref = engine.RefTables.from_texts(ann.ref_texts())
 e = engine.Engine(ref)
 e.chr_map_update(ann.chr_names, ann.chr_lens)
-for mask in [0, 0, 1, 2, 4, 8, 16, 1 | 2, 1 | 8, 2 | 4, 1 | 2 | 4 | 8 | 16, 2 | 4 | 8 | 16]:
+for mask in [0, 0, 1, 1 | 8, 1 | 2, 1 | 4, 1 | 16, 1 | 2 | 8, 1 | 2 | 4 | 8, 31, 30, 2 | 8]:
     os.environ["IRF_ABLATE"] = str(mask)
     e.reset(); e.submit(db)
     try:
