@@ -217,28 +217,24 @@ def main():
     out["known_reads"] = int(out["got"]["known_cnt"].to(torch.int64).sum().item())
 
     # ---------------- roofline of the dominant kernel (algorithmic bytes: SURVEY §8 d / DESIGN.md) ----------------
-    G = sum(((l + 1 + 63) // 64) * 64 for l, o in zip(lens, owned) if o)
-    meas_owned = 0
-    for l in ann.cover_bed.splitlines():
-        f = l.split("\t")
-        if owned[name_to_idx[f[0]]]:
-            meas_owned += sum(int(x) for x in f[10].split(",") if x)
+    lay = eng.layout()
+    G = lay["plane_positions"]            # per strand; only the buckets that hold measured intron bases are kept in HBM
     alg = {
         # input stream (13 B/fragment + 4 B CSR offset, 9 B/block) + two 4-byte difference-array targets per block
         "count_ms": n_frag * 17 + n_blk * 9 + n_blk * 2 * 4,
-        # depth scan: read 4 B + write 4 B per base and strand
-        "scan_ms": G * 2 * 8,
-        # statistics: 4 B per measured intron base and strand (non-directional table reads both strands)
-        "stats_ms": meas_owned * 2 * 4 * (2 if out.get("has_dir") else 1),
+        # depth carries: ONE read of the planes (4 B per kept position and strand); depth is never written back
+        "scan_ms": G * 2 * 4,
+        # statistics: 4 B per measured intron base and strand (both strands for the non-directional table)
+        "stats_ms": lay["measured_positions"] * 2 * 4,
     }
     dom = max(alg, key=lambda k: kt[k])
     achieved = alg[dom] / (kt[dom] * 1e-3) / 1e9 if kt[dom] > 0 else 0.0
     kernels = {k: {"ms": round(kt[k], 4), "alg_bytes": int(alg[k]), "GBps": round(alg[k] / (kt[k] * 1e-3) / 1e9, 1) if kt[k] > 0 else None}
                for k in alg}
     kernels["junction_ms"] = {"ms": round(kt["junction_ms"], 4)}
-    roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "reduce_tiles+scan_tiles", "stats_ms": "intron_stats_kernel"}[dom],
+    roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "segment_sums_kernel", "stats_ms": "intron_stats_kernel"}[dom],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "per_kernel": kernels}
+                "traffic": None, "per_kernel": kernels, "layout": lay}
 
     # ---------------- CPU baseline (oracle, bounded sample, 1 core) ----------------
     cpu = None

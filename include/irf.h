@@ -251,6 +251,15 @@ typedef enum irf_column {
 } irf_column;
 int irf_export_device(irf_ctx* ctx, uint32_t what, void* dst_device, uint64_t* n);
 
+/* HBM layout facts for roofline accounting (no upstream counterpart).       */
+typedef struct irf_layout {
+    uint64_t plane_positions;   /* positions per strand plane of the difference array (compact unless keep_depth) */
+    uint64_t full_positions;    /* size of the full coordinate space (owned references)                          */
+    uint64_t measured_positions;/* sum of measured bases over the introns this context finalises                 */
+    uint64_t junction_capacity; /* novel-junction event buffer, in events                                        */
+} irf_layout;
+int irf_get_layout(irf_ctx* ctx, irf_layout* out);
+
 /* Time (ms) the device spent in the named stage during the last
  * submit/finalize cycle, measured with HIP events on the engine's stream.   */
 typedef struct irf_timing {

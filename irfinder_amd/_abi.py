@@ -105,6 +105,10 @@ class IrfReaderStats(C.Structure):
                                           "n_pairs_intersect", "n_pairs_long", "n_skipped", "n_error")]
 
 
+class IrfLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("plane_positions", "full_positions", "measured_positions", "junction_capacity")]
+
+
 class IrfTiming(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("count_ms", "scan_ms", "stats_ms", "junction_ms", "table_ms",
                                          "total_finalize_ms")] + \

@@ -5,7 +5,7 @@
 // FragmentsInChr / FragmentsInROI / JunctionCount / SpansPoint and of
 // ReadBlockProcessor_CoverageBlocks.cpp CoverageBlocks (+ FragmentsMap):
 //   * FragmentsInChr : LDS histogram per workgroup, flushed with global atomics
-//   * FragmentsInROI : binary search over the (chr,end)-sorted ROI table
+//   * FragmentsInROI : bucket index over the end-sorted ROI table + short walk
 //   * CoverageBlocks : +1 / -1 into the per-strand difference array (depth comes
 //                      from the prefix scan at finalize)
 //   * SpansPoint     : bucket index over the plane + short walk of the sorted points
@@ -22,9 +22,9 @@ namespace dev {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
-constexpr int kFragsPerThread = 8;
+constexpr int kFragsPerThread = 2;
 constexpr int kChunk = kThreads * kFragsPerThread;   // fragments per workgroup iteration
 constexpr int kChrBins = 512;       // LDS histogram covers refIDs < 256; larger ones go straight to global
 constexpr uint32_t kJCache = 512;   // LDS cache of known-junction counters (direct-mapped on the table row)
@@ -174,19 +174,22 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
                 if (chr < kChrBins / 2) atomicAdd(&s_chr[chr * 2 + dir], 1u);
                 else atomicAdd(&T.chr_cnt[chr * 2 + dir], 1u);
             }
-            // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
-            if (!(T.ablate & 4u)) {
-                const uint32_t r0 = T.roi_off[chr], r1 = T.roi_off[chr + 1];
-                if (r1 > r0) {
-                    const uint32_t fs = B.frag_start[i], fe = B.frag_end[i];
-                    const uint32_t r = lower_bound_u32(T.roi_end, r0, r1, fe);
-                    if (r < r1 && T.roi_start[r] <= fs)
-                        atomicAdd(&T.roi_cnt[(uint64_t)dir * T.n_roi + T.roi_idx[r]], 1u);
-                }
-            }
-            // per aligned block
             const uint64_t base = T.chr_base[chr];
             const uint32_t clen = T.chr_len[chr];
+            const uint32_t fs = B.frag_start[i], fe = B.frag_end[i];
+            const bool extent_ok = fs <= fe && fe <= clen;
+            // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
+            if (!(T.ablate & 4u) && extent_ok && T.n_roi_dev) {
+                const uint64_t gfs = base + fs, gfe = base + fe;
+                uint32_t r = T.roi_bucket[gfe >> kBucketShift];
+                while (r < T.n_roi_dev && T.roi_gend[r] < gfe) r++;
+                if (r < T.n_roi_dev && T.roi_gstart[r] <= gfs)
+                    atomicAdd(&T.roi_cnt[(uint64_t)dir * T.n_roi + T.roi_idx[r]], 1u);
+            }
+            // SpansPoint: does any point lie under the fragment at all?  (two adjacent bucket entries)
+            const bool sp_any = !(T.ablate & 2u) &&
+                                (!extent_ok || T.sp_bucket[(base + fs) >> kBucketShift] != T.sp_bucket[((base + fe) >> kBucketShift) + 1]);
+            // per aligned block
             int32_t* tile = s_tile + dir * kWin;
             uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
             const uint32_t k0 = B.frag_blk_off[i], k1 = B.frag_blk_off[i + 1];
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
                     if (oe < kWin) atomicAdd(&tile[oe], -1);
                     else far_event(T, s_etag, s_ecnt, ge, dir, -1);
                 }
-                if (bs < be && !(T.ablate & 2u)) {
+                if (bs < be && sp_any) {
                     // SpansPoint
                     if (bl > T.sp_min_len) {
                         const uint64_t lo = base + bs + T.sp_lo_add, hi = base + be - T.sp_hi_sub;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;
     uint32_t blocks = (B.n_frag + kChunk - 1) / kChunk;
-    if (blocks > 256u * 6u) blocks = 256u * 6u;
+    if (blocks > 256u * 3u) blocks = 256u * 3u;
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, T, B);
 }
 

@@ -97,7 +97,9 @@ struct irf_ctx {
     DevBuf<uint32_t> d_chr_len;
     DevBuf<uint8_t> d_chr_owned;
     DevBuf<uint32_t> d_chr_cnt;
-    DevBuf<uint32_t> d_roi_off, d_roi_start, d_roi_end, d_roi_idx, d_roi_cnt;
+    DevBuf<uint32_t> d_roi_idx, d_roi_bucket, d_roi_cnt;
+    DevBuf<uint64_t> d_roi_gstart, d_roi_gend;
+    uint32_t n_roi_dev = 0;
     DevBuf<uint32_t> d_sp_row, d_sp_bucket, d_known_bucket, d_sp_cnt;
     DevBuf<uint64_t> d_sp_gpos;
     DevBuf<uint64_t> d_junc_a, d_junc_b;
@@ -120,6 +122,7 @@ struct irf_ctx {
     uint32_t n_kj = 0;
     unsigned long long votes[2] = {0, 0};
     uint64_t n_junction_events_total = 0;
+    uint64_t measured_valid = 0;
     DevBuf<uint32_t> d_left_cnt, d_right_cnt;
     uint32_t n_us = 0, n_ue = 0, n_known_dev = 0;
     DevBuf<double> d_out_f64[2];
@@ -268,6 +271,8 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             if (ref.blk_end[b] > chr_len[sl] || ref.blk_end[b] < ref.blk_start[b]) ok = false;
         in_valid[i] = ok;
     }
+    measured_valid = 0;
+    for (uint32_t i = 0; i < n_intron; i++) if (in_valid[i]) measured_valid += ref.in_measured[i];
     // plane layout: the whole coordinate space (keep_depth: FragmentsMap), or only the 512-position buckets that hold
     // measured intron bases (kernels.h: plane_coord)
     pmap.clear();
@@ -311,23 +316,37 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth carries / scan workspace failed");
     }
 
-    // ---- ROI: (slot,end)-sorted, BAM chromosomes only ----
+    // ---- ROI: owned chromosomes only, sorted by (slot,end) = by end in full coordinates; bucket index on the end ----
     n_roi = (uint32_t)ref.roi_start.size();
     {
         std::vector<uint32_t> idx;
-        for (uint32_t i = 0; i < n_roi; i++) if (refchr_slot[ref.roi_chr[i]] < n) idx.push_back(i);
+        for (uint32_t i = 0; i < n_roi; i++) {
+            const uint32_t sl = refchr_slot[ref.roi_chr[i]];
+            if (sl < n && chr_owned[sl] && ref.roi_start[i] <= ref.roi_end[i] && ref.roi_end[i] <= chr_len[sl]) idx.push_back(i);
+        }
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
             uint32_t sa = refchr_slot[ref.roi_chr[a]], sb = refchr_slot[ref.roi_chr[b]];
             if (sa != sb) return sa < sb;
             return ref.roi_end[a] < ref.roi_end[b];
         });
-        std::vector<uint32_t> offv(n + 1, 0), s, e, fi;
-        for (uint32_t i : idx) { offv[refchr_slot[ref.roi_chr[i]] + 1]++; s.push_back(ref.roi_start[i]); e.push_back(ref.roi_end[i]); fi.push_back(i); }
-        for (uint32_t i = 0; i < n; i++) offv[i + 1] += offv[i];
-        TRY(upload(this, d_roi_off, offv));
-        TRY(upload(this, d_roi_start, s));
-        TRY(upload(this, d_roi_end, e));
+        std::vector<uint64_t> gs, ge;
+        std::vector<uint32_t> fi;
+        for (uint32_t i : idx) {
+            const uint64_t base = chr_base[refchr_slot[ref.roi_chr[i]]];
+            gs.push_back(base + ref.roi_start[i]); ge.push_back(base + ref.roi_end[i]); fi.push_back(i);
+        }
+        n_roi_dev = (uint32_t)fi.size();
+        const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
+        std::vector<uint32_t> bucket(nb);
+        size_t p = 0;
+        for (uint64_t b = 0; b < nb; b++) {
+            while (p < ge.size() && ge[p] < (b << dev::kBucketShift)) p++;
+            bucket[b] = (uint32_t)p;
+        }
+        TRY(upload(this, d_roi_gstart, gs));
+        TRY(upload(this, d_roi_gend, ge));
         TRY(upload(this, d_roi_idx, fi));
+        TRY(upload(this, d_roi_bucket, bucket));
         TRY(alloc_zero(this, d_roi_cnt, (size_t)n_roi * 2));
     }
     // ---- SpansPoint: (slot,pos)-sorted; reference-only chromosomes at the tail ----
@@ -515,7 +534,8 @@ dev::CountTables irf_ctx::count_tables() {
     T.junc_capacity = d_junc_a.cap;
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
     T.diff = d_diff.p; T.chr_cnt = d_chr_cnt.p;
-    T.roi_off = d_roi_off.p; T.roi_start = d_roi_start.p; T.roi_end = d_roi_end.p; T.roi_idx = d_roi_idx.p; T.roi_cnt = d_roi_cnt.p;
+    T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p; T.roi_bucket = d_roi_bucket.p;
+    T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
     T.sp_gpos = d_sp_gpos.p; T.sp_row = d_sp_row.p; T.sp_bucket = d_sp_bucket.p; T.sp_cnt = d_sp_cnt.p;
     T.known_keys = d_known_keys.p; T.known_bucket = d_known_bucket.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
     T.junc_keys = d_junc_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
@@ -1078,6 +1098,16 @@ int irf_host_alloc(size_t bytes, void** out) {
     return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : IRF_E_NOMEM;
 }
 void irf_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int irf_get_layout(irf_ctx* c, irf_layout* out) {
+    if (!c || !out) return IRF_E_ARG;
+    if (!c->have_map) return c->fail(IRF_E_STATE, "irf_get_layout before irf_chr_map_update");
+    out->plane_positions = c->plane_stride;
+    out->full_positions = c->full_size;
+    out->measured_positions = c->measured_valid;
+    out->junction_capacity = c->d_junc_a.cap;
+    return 0;
+}
 
 int irf_get_timing(irf_ctx* c, irf_timing* out) {
     if (!c || !out) return IRF_E_ARG;

@@ -55,10 +55,13 @@ struct CountTables {
     const uint8_t* chr_owned;  // [n_chr]
     int32_t* diff;             // [2][plane_stride]  +1 at block start, -1 at block end
     uint32_t* chr_cnt;         // [n_chr][2]
-    const uint32_t* roi_off;   // [n_chr+1] into the (chr,end)-sorted ROI arrays
-    const uint32_t* roi_start;
-    const uint32_t* roi_end;
-    const uint32_t* roi_idx;   // file index of the sorted ROI
+    // ROIs of owned chromosomes sorted by end, in full coordinates, + bucket index on the end
+    const uint64_t* roi_gstart;
+    const uint64_t* roi_gend;
+    const uint32_t* roi_idx;    // file index of the sorted ROI
+    const uint32_t* roi_bucket; // [(full_size >> kBucketShift) + 2] first ROI with gend >= b << kBucketShift
+    uint32_t n_roi_dev;
+    uint32_t pad2;
     uint32_t* roi_cnt;         // [2][n_roi]
     // SpansPoint: points on owned chromosomes in plane coordinates + a bucket index over the plane
     // (sp_bucket[b] = first point with gpos >= b << kBucketShift), so a block costs two adjacent loads when no

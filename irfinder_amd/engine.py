@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from ._abi import (STATUS, Batch, IrfBatch, IrfParams, IrfReaderStats, IrfResults, IrfTiming, IRF_MEM_DEVICE,
+from ._abi import (STATUS, Batch, IrfBatch, IrfLayout, IrfParams, IrfReaderStats, IrfResults, IrfTiming, IRF_MEM_DEVICE,
                    IRF_MEM_HOST, results_to_dict)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -82,6 +82,7 @@ def lib():
     L.irf_reset.argtypes = [vp]
     L.irf_export_device.argtypes = [vp, u32, C.c_void_p, C.POINTER(u64)]
     L.irf_get_timing.argtypes = [vp, C.POINTER(IrfTiming)]
+    L.irf_get_layout.argtypes = [vp, C.POINTER(IrfLayout)]
     L.irf_reader_create.argtypes = [C.POINTER(IrfParams), C.POINTER(vp)]
     L.irf_reader_destroy.argtypes = [vp]
     L.irf_reader_destroy.restype = None
@@ -300,6 +301,11 @@ class Engine:
         t = IrfTiming()
         self._chk(self.L.irf_get_timing(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in IrfTiming._fields_ if n != "reserved"}
+
+    def layout(self):
+        t = IrfLayout()
+        self._chk(self.L.irf_get_layout(self.h, C.byref(t)))
+        return {n: int(getattr(t, n)) for n, _ in IrfLayout._fields_}
 
     def export_size(self, what):
         n = C.c_uint64()
