@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=2_000_000, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "8")))
     ap.add_argument("--no-decode-bench", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --one-device rehearses the N>1 path on a single GPU (tables cross the host)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,10 +73,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     # ---------------- workload ----------------
     cfg_idx = 2 if args.stranded else 1
@@ -145,7 +154,7 @@ def main():
         eng.finalize()
         t_c = time.perf_counter()
         if world > 1:       # the strandedness vote is global: one all-reduce of two integers
-            v = torch.tensor(eng.votes(), dtype=torch.int64, device=dev)
+            v = torch.tensor(eng.votes(), dtype=torch.int64, device=coll_dev)
             eng.finalize_directional(irfdist.global_directionality(v, dist, eng.params.dir_ratio))
         tabs = {
             "ir_f64": export(COL_IR_NONDIR_F64, (8, n_in), torch.float64),
@@ -164,6 +173,8 @@ def main():
             irfdist.mask_unowned_rows(tabs["ir_f64"], tabs["ir_u32"], intron_owned)
             if "ir_dir_f64" in tabs:
                 irfdist.mask_unowned_rows(tabs["ir_dir_f64"], tabs["ir_dir_u32"], intron_owned)
+            if coll_dev.type == "cpu":
+                tabs = {k: t.cpu() for k, t in tabs.items()}
             got = irfdist.gather_tables(tabs, dist)
         else:
             got = irfdist.gather_tables(tabs, None)
@@ -201,7 +212,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / max(args.steps, 1) * 1e3

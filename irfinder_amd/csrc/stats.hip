@@ -7,9 +7,9 @@
 // std::map<depth,count> per intron and walks it; every statistic is a function
 // of the multiset of depths over the intron's measured bases, so here one
 // workgroup per intron answers a handful of rank queries ("value at rank r" and
-// "sum of the r smallest values") exactly, with an 11-bit-per-level radix
+// "sum of the r smallest values") exactly, with a 10-bit-per-level radix
 // select over an LDS histogram:
-//   depth < 2048 (the common case): ONE pass over the depth values;
+//   depth < 1024 (the common case): ONE pass over the depth values;
 //   deeper introns: one filtered pass per level and query (rare).
 // The integers that come out are identical to what the map walk yields; the
 // few fp64 operations (divisions, one interpolation) are done in the same order
@@ -36,7 +36,7 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kBinBits = 10;
 constexpr int kBins = 1 << kBinBits;
-constexpr int kBinsPerThread = kBins / kThreads;   // 8
+constexpr int kBinsPerThread = kBins / kThreads;   // 4
 constexpr int kMaxFlank = 512;
 constexpr int kQueries = 8;
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)

@@ -281,3 +281,64 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
         assert files == sorted(os.listdir(out)) and len(files) == 6, tag
         for f in files:
             assert filecmp.cmp(out / f, cpu / f, shallow=False), (tag, f)
+
+
+def test_chromosome_shards_sum_to_the_whole_P3():
+    """Two contexts with complementary `owned` masks (what two ranks do), each fed the WHOLE batch (foreign fragments
+    are ignored), the global strandedness vote imposed on both: the owner's rows / counters equal the single run's."""
+    from irfinder_amd import distributed as irfdist
+    ann, sim = small_world(seed=19, stranded=True, n_chr=4)
+    names, lens, batch = read_batch(sim.bam(0, 30000))
+    e, whole = run_gpu(ann.ref_texts(), names, lens, [batch])
+    masks = irfdist.shard_chromosomes(lens, 2)
+    parts = []
+    votes = np.zeros(2, np.int64)
+    for m in masks:
+        ref = engine.RefTables.from_texts(ann.ref_texts())
+        ei = engine.Engine(ref)
+        ei.chr_map_update(names, lens, m)
+        ei.process(batch)
+        ei.finalize()
+        votes += np.array(ei.votes(), np.int64)
+        parts.append(ei)
+    d = 1 if votes[0] > votes[1] * 10 else (-1 if votes[1] > votes[0] * 10 else 0)
+    assert d == whole["directionality"] != 0
+    res = []
+    for ei in parts:
+        ei.finalize_directional(d)
+        res.append(ei.results())
+    name_to_idx = {n: i for i, n in enumerate(names)}
+    in_chr = np.array([name_to_idx[l.split("\t", 1)[0]] for l in ann.cover_bed.splitlines()])
+    for tname in ("nondir", "dir"):
+        for k in whole[tname]:
+            merged = np.where(masks[0][in_chr] == 1, res[0][tname][k], res[1][tname][k])
+            assert np.array_equal(merged, whole[tname][k]), (tname, k)
+    for k in ("chr_cnt", "roi_cnt", "sp_cnt", "junc_cnt"):
+        assert np.array_equal(res[0][k] + res[1][k], whole[k]), k
+    assert res[0]["n_fragments"] == res[1]["n_fragments"] == batch.n_frag       # submitted, not counted
+
+
+def test_chr22_scale_matches_oracle_and_properties():
+    """BASELINE configs[0] shape (2 M simulated 2x100 pairs, chr22-sized reference, unstranded) — the largest size the
+    oracle finishes in seconds — bit-exact, plus the size-independent properties used at the full bench size:
+    P4 nondir = pos + neg (via the directional planes of a stranded twin), P5 sum of FragmentsInChr = fragments,
+    P6 SpliceLeft/Right are sums of junction rows."""
+    from irfinder_amd.synth import world as synth_world
+    from irfinder_amd.synth.annotation import GRCH38, make_annotation
+    from irfinder_amd.synth.reads import ReadSimulator
+    ann = make_annotation([GRCH38[21]], seed=20240807)
+    sim = ReadSimulator(ann, read_len=100, seed=20240807)
+    batches, st = synth_world.generate_batches(sim, 0, 2_000_000, chunk=250_000, threads=8)
+    whole = synth_world.sort_by_coordinate(synth_world.concat_batches(batches))
+    e, g = run_gpu(ann.ref_texts(), ann.chr_names, ann.chr_lens, [whole])
+    o, c = run_orc(ann.ref_texts(), ann.chr_names, ann.chr_lens, batches)          # oracle sees the unsorted chunks
+    assert_results_equal(g, c, rel=0.0, what="chr22 2M pairs")
+    assert g["chr_cnt"].sum() == whole.n_frag == st["n_pairs"] + st["n_singles"]
+    # P6 on the device result: SpliceLeft of an intron = sum over junction rows sharing its start
+    starts = np.array([int(l.split("\t")[1]) for l in ann.cover_bed.splitlines()])
+    left_sum = {}
+    tot = g["junc_cnt"].sum(axis=0)
+    for l, t in zip(g["junc_left"], tot):
+        left_sum[int(l)] = left_sum.get(int(l), 0) + int(t)
+    exp = np.array([left_sum.get(int(s), 0) for s in starts])
+    assert np.array_equal(exp, g["nondir"]["splice_left"])
