@@ -100,7 +100,8 @@ struct irf_ctx {
     DevBuf<uint32_t> d_roi_idx, d_roi_bucket, d_roi_cnt;
     DevBuf<uint64_t> d_roi_gstart, d_roi_gend;
     uint32_t n_roi_dev = 0;
-    DevBuf<uint32_t> d_sp_row, d_sp_bucket, d_known_bucket, d_sp_cnt;
+    DevBuf<uint32_t> d_sp_row, d_sp_cnt;
+    DevBuf<uint4> d_bkt;                         // kernels.h: CountTables::bkt
     DevBuf<uint64_t> d_sp_gpos;
     DevBuf<uint64_t> d_junc_a, d_junc_b;
     DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
@@ -351,6 +352,8 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     }
     // ---- SpansPoint: (slot,pos)-sorted; reference-only chromosomes at the tail ----
     n_sp = (uint32_t)ref.sp_pos.size();
+    std::vector<uint32_t> sp_bucket_h;
+    size_t n_sp_dev = 0;
     {
         std::vector<uint64_t> key(n_sp);
         for (uint32_t i = 0; i < n_sp; i++) key[i] = ((uint64_t)refchr_slot[ref.sp_chr[i]] << 32) | ref.sp_pos[i];
@@ -375,9 +378,10 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
                 bucket[b] = (uint32_t)p;
             }
         }
+        n_sp_dev = gpos.size();
         TRY(upload(this, d_sp_gpos, gpos));
         TRY(upload(this, d_sp_row, row));
-        TRY(upload(this, d_sp_bucket, bucket));
+        sp_bucket_h.swap(bucket);
         TRY(alloc_zero(this, d_sp_cnt, (size_t)n_sp * 2));
     }
     // ---- known junctions sorted by (slot,left,right) ----
@@ -414,7 +418,20 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
                 while (p < kkeys.size() && (kkeys[p] >> dev::kJuncSpanBits) < (b << dev::kBucketShift)) p++;
                 bucket[b] = (uint32_t)p;
             }
-            TRY(upload(this, d_known_bucket, bucket));
+            // the count kernel's bucket table: plane map + SpansPoint range + known-junction range per bucket
+            std::vector<uint4> bk(nb);
+            auto cnt16 = [](const std::vector<uint32_t>& v, uint64_t b, size_t total) -> uint32_t {
+                const uint64_t n = (b + 1 < v.size() ? v[b + 1] : (uint32_t)total) - (uint64_t)v[b];
+                return n < 0xffffull ? (uint32_t)n : 0xffffu;
+            };
+            for (uint64_t b = 0; b < nb; b++) {
+                bk[b].x = pmap.empty() ? 0u : pmap[b];
+                bk[b].y = sp_bucket_h[b];
+                bk[b].z = bucket[b];
+                bk[b].w = cnt16(sp_bucket_h, b, n_sp_dev) | (cnt16(bucket, b, kkeys.size()) << 16);
+            }
+            TRY(upload(this, d_bkt, bk));
+            std::vector<uint32_t>().swap(sp_bucket_h);
         }
         TRY(upload(this, d_known_keys, kkeys));
         TRY(upload(this, d_known_dir, kdir));
@@ -536,8 +553,8 @@ dev::CountTables irf_ctx::count_tables() {
     T.diff = d_diff.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p; T.roi_bucket = d_roi_bucket.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
-    T.sp_gpos = d_sp_gpos.p; T.sp_row = d_sp_row.p; T.sp_bucket = d_sp_bucket.p; T.sp_cnt = d_sp_cnt.p;
-    T.known_keys = d_known_keys.p; T.known_bucket = d_known_bucket.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
+    T.sp_gpos = d_sp_gpos.p; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
+    T.known_keys = d_known_keys.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
     T.junc_keys = d_junc_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
     return T;
 }

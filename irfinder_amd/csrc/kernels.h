@@ -49,6 +49,11 @@ struct CountTables {
     uint64_t plane_stride;     // elements per strand plane of the difference array (compact coordinates)
     uint64_t full_size;        // size of the full coordinate space (chr_base + pos); junction keys, point / junction buckets
     const uint32_t* pmap;      // full -> plane coordinates, one entry per 512-position bucket; nullptr = identity
+    // everything the count kernel needs to know about a 512-position bucket of the full coordinate space, in one
+    // 16-byte load: x = pmap entry, y = first SpansPoint at or after the bucket start, z = first known-junction key
+    // whose left end is at or after the bucket start, w = (points in the bucket) | (known keys in the bucket) << 16,
+    // each saturating at 0xffff (then the next entry's y / z closes the range).  [(full_size >> kBucketShift) + 2]
+    const uint4* bkt;
     uint64_t junc_capacity;
     const uint64_t* chr_base;  // [n_chr]  offset of the chromosome inside a plane
     const uint32_t* chr_len;   // [n_chr]
@@ -63,17 +68,13 @@ struct CountTables {
     uint32_t n_roi_dev;
     uint32_t pad2;
     uint32_t* roi_cnt;         // [2][n_roi]
-    // SpansPoint: points on owned chromosomes in plane coordinates + a bucket index over the plane
-    // (sp_bucket[b] = first point with gpos >= b << kBucketShift), so a block costs two adjacent loads when no
-    // point is near (the common case) instead of a 19-step binary search
+    // SpansPoint: points on owned chromosomes in full coordinates (range per bucket: bkt)
     const uint64_t* sp_gpos;   // [n_sp_own] sorted
     const uint32_t* sp_row;    // [n_sp_own] row in sp_cnt
-    const uint32_t* sp_bucket; // [plane_stride >> kBucketShift) + 2]
     uint32_t* sp_cnt;          // [2][n_sp]
     // known junctions (ref-sj.ref) on owned chromosomes: events that hit one are counted in place,
     // only novel junctions go through the event buffer + sort
     const uint64_t* known_keys;   // sorted (global_left << 28 | span)
-    const uint32_t* known_bucket; // [(plane_stride >> kBucketShift) + 2] first known key with global_left >= b << kBucketShift
     const uint32_t* known_kjidx;  // row of the known-junction table (all of ref-sj, (slot,left,right) order)
     uint32_t n_known;             // entries of known_keys
     uint32_t n_kj;                // rows of the known-junction table

@@ -13,7 +13,7 @@ from ._abi import (STATUS, Batch, IrfBatch, IrfLayout, IrfParams, IrfReaderStats
                    IRF_MEM_HOST, results_to_dict)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libirfhip.so")
+LIB_PATH = os.environ.get("IRF_LIB_PATH") or os.path.join(_HERE, "libirfhip.so")   # IRF_LIB_PATH: kernel-tuning builds only
 _LIB = None
 
 

@@ -24,7 +24,8 @@ db = engine.device_batch(dten, host.n_frag, host.n_blk)
 ref = engine.RefTables.from_texts(ann.ref_texts())
 e = engine.Engine(ref)
 e.chr_map_update(ann.chr_names, ann.chr_lens)
-for mask in [0, 0, 1, 1 | 8, 1 | 2, 1 | 4, 1 | 16, 1 | 2 | 8, 1 | 2 | 4 | 8, 31, 30, 2 | 8]:
+masks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 0, 1, 1 | 8, 1 | 2, 1 | 4, 1 | 16, 1 | 2 | 8, 1 | 2 | 4 | 8, 31, 30, 2 | 8]
+for mask in masks:
     os.environ["IRF_ABLATE"] = str(mask)
     e.reset(); e.submit(db)
     try:
