@@ -14,19 +14,24 @@
 //                      are appended as packed (chr,left,span,strand) events to a
 //                      buffer and sort-reduced at finalize
 // All outputs are commutative integer sums, so any batch order gives identical
-// results.  HBM-/latency-bound integer work: no MFMA.
+// results.  Integer work bound by memory latency and by the atomic rate: no MFMA.
 //
-// Shape of the kernel.  The input is CSR (fragments -> blocks); walking it fragment by fragment gives every lane a
-// chain of dependent loads (offset -> block -> bucket table -> counters) of data-dependent length, and the kernel
-// then waits on memory 85 % of its cycles.  So a workgroup processes a chunk of kChunk consecutive fragments in two
-// bulk phases:
-//   1. fragment-parallel: the fragment columns are read coalesced; per-fragment facts (chromosome base, strand,
-//      chromosome length, CSR offset) go to LDS; FragmentsInChr and FragmentsInROI are done here;
-//   2. block-parallel: the chunk's blocks are one contiguous range of the block columns, read coalesced, kUnroll
-//      independent blocks per lane in flight; the owning fragment comes from a binary search of the LDS offsets;
-//      ONE 16-byte bucket-table entry per block end gives the plane map, the SpansPoint range and the known-junction
-//      range; a block owns the junction to its right;
-//   3. the LDS accumulators (difference window, far-event cache, junction cache, novel-junction queue) are flushed.
+// Shape of the kernel.  The input is CSR (fragments -> blocks).  A workgroup processes a chunk of kChunk consecutive
+// fragments in bulk phases, so that every lane has many independent, wide loads in flight:
+//   1. fragment-parallel, 4 consecutive fragments per lane (16-byte loads of the fragment columns): per-fragment
+//      facts (chromosome base, strand, chromosome length, CSR offset) go to LDS; FragmentsInChr and
+//      FragmentsInROI are done here;
+//   2. block-parallel, 4 consecutive blocks per lane (16-byte loads of the block columns): the owning fragment comes
+//      from a binary search of the LDS offsets; ONE 16-byte bucket-table entry per block end gives the plane map,
+//      the SpansPoint range and the known-junction range.  A block owns the junction to its right, and with it
+//      the two difference events next to that junction (its own end, its successor's start): a read on a known
+//      junction costs one wave-aggregated LDS increment of that junction's counter, and the junction's two
+//      difference events are emitted once per chunk from the counter;
+//   3. the LDS accumulators are flushed with global atomics shaped for the memory-side atomic unit (consecutive
+//      lanes = consecutive cells, whole 64-byte lines): the difference window (both strands packed in one int32
+//      per position), the line-granular cache of far events, the junction cache, the novel-junction queue.
+// Loads are unconditional on clamped indices: a conditional load compiles to a branch with a full vmcnt wait
+// behind it, which serialises the round trips.
 #include "kernels.h"
 
 namespace irf {
@@ -35,56 +40,58 @@ namespace dev {
 namespace {
 
 #ifndef K_THREADS
-#define K_THREADS 512
-#endif
-#ifndef K_FPT
-#define K_FPT 2
-#endif
-#ifndef K_UNROLL
-#define K_UNROLL 2
+#define K_THREADS 256
 #endif
 #ifndef K_WIN
 #define K_WIN 4096
 #endif
-#ifndef K_ECACHE
-#define K_ECACHE 1024
+#ifndef K_LINES
+#define K_LINES 128
 #endif
 #ifndef K_JCACHE
-#define K_JCACHE 512
+#define K_JCACHE 256
 #endif
 #ifndef K_NOVELQ
-#define K_NOVELQ 512
+#define K_NOVELQ 256
 #endif
 #ifndef K_WGS_PER_CU
-#define K_WGS_PER_CU 2
+#define K_WGS_PER_CU 3
+#endif
+#ifndef K_MIN_WGS
+#define K_MIN_WGS 1
 #endif
 constexpr int kThreads = K_THREADS;
-constexpr int kFragsPerThread = K_FPT;
-constexpr int kChunk = kThreads * kFragsPerThread;   // fragments per workgroup iteration
-constexpr int kChunkLog2 = kChunk == 1024 ? 10 : kChunk == 512 ? 9 : kChunk == 256 ? 8 : kChunk == 2048 ? 11 : 0;
-static_assert((1 << kChunkLog2) == kChunk, "kChunkLog2");
-constexpr int kUnroll = K_UNROLL;          // blocks in flight per lane in phase 2
+constexpr int kVec = 4;                               // consecutive fragments / blocks per lane
+constexpr int kChunk = kThreads * kVec;               // fragments per workgroup iteration
+constexpr int kChunkLog2 = kChunk == 1024 ? 10 : kChunk == 2048 ? 11 : kChunk == 512 ? 9 : 0;
+static_assert(kChunkLog2 > 0, "K_THREADS");
 constexpr int kChrBins = 512;       // LDS histogram covers refIDs < 256; larger ones go straight to global
 constexpr uint32_t kJCache = K_JCACHE;   // LDS cache of known-junction counters (direct-mapped on the known-key index)
 constexpr uint32_t kEmpty = 0xffffffffu;
-constexpr uint32_t kECache = K_ECACHE;  // LDS cache of difference events outside the window (direct-mapped on plane address)
-constexpr int kECacheBits = kECache == 1024 ? 10 : kECache == 512 ? 9 : kECache == 2048 ? 11 : kECache == 256 ? 8 : 0;
-static_assert(kECacheBits > 0, "K_ECACHE");
-constexpr uint32_t kWin = K_WIN;     // positions of the LDS difference-array window (per strand)
+constexpr uint32_t kLines = K_LINES;     // LDS cache of 16-position lines of the difference planes outside the window
+constexpr uint32_t kWin = K_WIN;         // positions of the LDS difference-array window (both strands in one int32)
+constexpr uint32_t kPCache = 128;         // LDS cache of SpansPoint counters (direct-mapped on the point index)
 constexpr uint32_t kNovelQ = K_NOVELQ;   // LDS queue of novel-junction events per chunk
-constexpr unsigned long long kFragValid = 1ull << 63, kFragDir = 1ull << 62, kFragBaseMask = (1ull << 40) - 1ull;
+constexpr uint32_t kWinMaxBlocks = 16000;   // more blocks than this in one chunk: a packed 16-bit counter could overflow
+constexpr uint32_t kFragValid = 1u << 31, kFragDir = 1u << 30, kFragBaseMask = (1u << 30) - 1u;   // base is a multiple of 64
 
-// A difference event outside the chunk's window (typically the far side of a splice: many reads of a chunk share
-// the same exon boundary).  Direct-mapped LDS cache on the plane address; a slot held by another address falls
-// through to a global atomic.
-__device__ __forceinline__ void far_event(const CountTables& T, uint32_t* s_etag, int32_t* s_ecnt, uint64_t g, uint32_t dir, int v) {
-    const uint64_t gd = g * 2u + dir;
-    const uint32_t c = (uint32_t)gd & (kECache - 1), want = (uint32_t)(gd >> kECacheBits);
-    uint32_t tag = s_etag[c];
-    if (tag == kEmpty) { const uint32_t old = atomicCAS(&s_etag[c], kEmpty, want); tag = old == kEmpty ? want : old; }
-    if (tag == want) atomicAdd(&s_ecnt[c], v);
-    else __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+struct Lds {
+    uint32_t off[kChunk + 4];          // CSR offsets of the chunk's fragments (clamped to n_blk); [kChunk] = end
+    uint32_t fb[kChunk];               // chr_base >> 6 | strand << 30 | counted << 31
+    uint32_t fclen[kChunk];            // chromosome length
+    int32_t tile[kWin];                // difference window: low half strand 0, high half strand 1
+    uint32_t ltag[kLines];             // far-event line cache: (plane position >> 4) * 2 + strand
+    int32_t lcnt[kLines][16];
+    uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
+    uint32_t jcnt[2][kJCache];
+    uint2 jpos[kJCache];               // plane positions of the junction's two difference events
+    uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_gpos
+    uint32_t pcnt[2][kPCache];
+    unsigned long long nq[kNovelQ];
+    uint32_t chr[kChrBins];
+    unsigned long long win, nq_base;
+    uint32_t nq_n, wmax;
+};
 
 __device__ __forceinline__ uint64_t plane_of(const CountTables& T, uint32_t m, uint64_t g) {
     if (!T.pmap) return g;
@@ -92,30 +99,69 @@ __device__ __forceinline__ uint64_t plane_of(const CountTables& T, uint32_t m, u
     return (m & 1u) ? c + (g & ((1u << kBucketShift) - 1u)) : c;
 }
 
-__global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev B) {
-    __shared__ uint32_t s_off[kChunk + 1];               // CSR offsets of the chunk's fragments (clamped to n_blk)
-    __shared__ unsigned long long s_fbase[kChunk];       // chr_base | strand << 62 | counted << 63
-    __shared__ uint32_t s_fclen[kChunk];                 // chromosome length
-    __shared__ __align__(16) int32_t s_tile[2 * kWin];
-    __shared__ uint32_t s_etag[kECache];
-    __shared__ int32_t s_ecnt[kECache];
-    __shared__ uint32_t s_jtag[kJCache];
-    __shared__ uint32_t s_jcnt[2][kJCache];
-    __shared__ unsigned long long s_nq[kNovelQ];
-    __shared__ uint32_t s_chr[kChrBins];
-    __shared__ unsigned long long s_win, s_nq_base;
-    __shared__ uint32_t s_nq_n, s_wmax;
+// One difference event at plane position c: the chunk's LDS window if it is inside, else the line cache, else
+// (line slot taken by another line) a global atomic.
+__device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsigned long long win, bool use_win, uint64_t c,
+                                            uint32_t dir, int v, uint32_t& wmax) {
+    const uint64_t o = c - win;
+    if (use_win && o < kWin) {
+        atomicAdd(&S.tile[o], dir ? v * 65536 : v);
+        wmax = (uint32_t)o > wmax ? (uint32_t)o : wmax;
+        return;
+    }
+#ifdef K_NOLINES
+    __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+#endif
+    const uint32_t want = (uint32_t)(c >> 4) * 2u + dir;
+    const uint32_t slot = ((uint32_t)(c >> 4) ^ (dir * (kLines / 2u))) & (kLines - 1u);
+    uint32_t tag = S.ltag[slot];
+    if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ltag[slot], kEmpty, want); tag = old == kEmpty ? want : old; }
+    if (tag == want) atomicAdd(&S.lcnt[slot][c & 15u], v);
+    else __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// n reads of strand dir on known junction idx (difference events at plane positions cl / cr): the chunk's LDS
+// counter (true), or straight to the table (false: the caller then emits the reads' difference events itself)
+__device__ __forceinline__ bool junction_add(const CountTables& T, Lds& S, uint32_t idx, uint32_t dir, uint32_t n, uint64_t cl, uint64_t cr) {
+    const uint32_t slot = idx & (kJCache - 1u);
+    uint32_t tag = S.jtag[slot];
+    if (tag == kEmpty) {
+        const uint32_t old = atomicCAS(&S.jtag[slot], kEmpty, idx);
+        tag = old == kEmpty ? idx : old;
+    }
+    if (tag == idx) {
+        S.jpos[slot] = make_uint2((uint32_t)cl, (uint32_t)cr);      // every writer of the slot writes the same pair
+        atomicAdd(&S.jcnt[dir][slot], n);
+        return true;
+    }
+    atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + T.known_kjidx[idx]], n);
+    return false;
+}
+
+__global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables T, BatchDev B) {
+    __shared__ __align__(16) Lds S;
     const uint32_t tid = threadIdx.x;
-    for (int k = tid; k < kChrBins; k += kThreads) s_chr[k] = 0;
-    for (int k = tid; k < (int)(2 * kWin); k += kThreads) s_tile[k] = 0;
-    for (int k = tid; k < (int)kECache; k += kThreads) { s_etag[k] = kEmpty; s_ecnt[k] = 0; }
-    for (int k = tid; k < (int)kJCache; k += kThreads) { s_jtag[k] = kEmpty; s_jcnt[0][k] = 0; s_jcnt[1][k] = 0; }
-    if (tid == 0) { s_nq_n = 0; s_wmax = 0; }
+    for (int k = tid; k < kChrBins; k += kThreads) S.chr[k] = 0;
+    for (int k = tid; k < (int)kWin; k += kThreads) S.tile[k] = 0;
+    for (int k = tid; k < (int)kLines; k += kThreads) S.ltag[k] = kEmpty;
+    for (int k = tid; k < (int)kLines * 16; k += kThreads) S.lcnt[k >> 4][k & 15] = 0;
+    for (int k = tid; k < (int)kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
+    for (int k = tid; k < (int)kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
+    if (tid == 0) { S.nq_n = 0; S.wmax = 0; }
     __syncthreads();
 
     const uint32_t lane = tid & 63u;
     uint32_t err = 0;
     const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
+    const uint4* __restrict__ chr4 = reinterpret_cast<const uint4*>(B.frag_chr);
+    const uint4* __restrict__ fs4 = reinterpret_cast<const uint4*>(B.frag_start);
+    const uint4* __restrict__ fe4 = reinterpret_cast<const uint4*>(B.frag_end);
+    const uint4* __restrict__ off4 = reinterpret_cast<const uint4*>(B.frag_blk_off);
+    const uint32_t* __restrict__ flg4 = reinterpret_cast<const uint32_t*>(B.frag_flags);
+    const uint4* __restrict__ bs4 = reinterpret_cast<const uint4*>(B.blk_start);
+    const uint4* __restrict__ bl4 = reinterpret_cast<const uint4*>(B.blk_len);
+    const uint32_t* __restrict__ rd4 = reinterpret_cast<const uint32_t*>(B.blk_read);
     // XCD-aware chunk order: workgroup b runs on XCD b % 8 (round-robin dispatch); every XCD gets a contiguous
     // eighth of the (coordinate-sorted) batch, so that neighbouring chunks — same table lines, overlapping
     // difference windows — share one L2
@@ -124,74 +170,70 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
     const uint32_t c_end = (xcd + 1u) * per_xcd < n_chunks ? (xcd + 1u) * per_xcd : n_chunks;
     for (uint32_t c = xcd * per_xcd + wg_in_xcd; c < c_end; c += wgs_per_xcd) {
         const uint32_t f0 = c * kChunk;
-        // ---------------- 1. fragment-parallel ----------------
+        // ---------------- 1. fragment-parallel: fragments f0 + 4 tid .. + 3 ----------------
         {
-            uint32_t chr[kFragsPerThread], fs[kFragsPerThread], fe[kFragsPerThread], off[kFragsPerThread], flg[kFragsPerThread];
-#pragma unroll
-            for (int j = 0; j < kFragsPerThread; j++) {
-                // loads are unconditional on a clamped index (a conditional load becomes a branch with a full wait
-                // behind it, which serialises the round trips); the values of lanes past the end are discarded
-                const uint32_t i = f0 + j * kThreads + tid;
-                const bool in = i < B.n_frag;
-                const uint32_t ic = in ? i : B.n_frag - 1u;
-                chr[j] = B.frag_chr[ic];
-                flg[j] = B.frag_flags[ic];
-                fs[j] = B.frag_start[ic];
-                fe[j] = B.frag_end[ic];
-                off[j] = B.frag_blk_off[in ? i : B.n_frag];
-                if (!in) chr[j] = kEmpty;
-            }
+            // a 16-byte group that starts inside an array never leaves the array's last page: lanes past the end read
+            // the last group again and discard it
+            const uint32_t g_last = (B.n_frag - 1u) >> 2;
+            const uint32_t g = (f0 >> 2) + tid < g_last ? (f0 >> 2) + tid : g_last;
+            const uint4 vchr = chr4[g], vfs = fs4[g], vfe = fe4[g], voff = off4[g];
+            const uint32_t vflg = flg4[g];
             if (tid == 0) {
                 const uint32_t last = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
                 const uint32_t o = B.frag_blk_off[last];
-                s_off[kChunk] = o < B.n_blk ? o : B.n_blk;
+                S.off[kChunk] = o < B.n_blk ? o : B.n_blk;
             }
-            uint32_t key[kFragsPerThread], clen[kFragsPerThread];
-            uint64_t base[kFragsPerThread];
+            const uint32_t chr[kVec] = {vchr.x, vchr.y, vchr.z, vchr.w};
+            const uint32_t fs[kVec] = {vfs.x, vfs.y, vfs.z, vfs.w}, fe[kVec] = {vfe.x, vfe.y, vfe.z, vfe.w};
+            const uint32_t off[kVec] = {voff.x, voff.y, voff.z, voff.w};
+            uint32_t key[kVec], clen[kVec];
+            uint64_t base[kVec];
+            bool in[kVec];
 #pragma unroll
-            for (int j = 0; j < kFragsPerThread; j++) {
-                const bool in = (f0 + j * kThreads + tid) < B.n_frag;
-                const bool ok = chr[j] < T.n_chr;
-                if (in && !ok) err |= ERR_CHR_RANGE;
-                const uint32_t cc = ok ? chr[j] : 0u;            // tables hold at least one entry
+            for (int j = 0; j < kVec; j++) {
+                const uint32_t i = f0 + tid * kVec + j;
+                in[j] = i < B.n_frag;
+                const bool ok = in[j] && chr[j] < T.n_chr;
+                if (in[j] && !ok) err |= ERR_CHR_RANGE;
+                const uint32_t cc = ok ? chr[j] : 0u;            // the tables hold at least one entry
                 const bool counted = (T.chr_owned[cc] != 0) && ok;
                 base[j] = T.chr_base[cc];
                 clen[j] = T.chr_len[cc];
                 if (!counted) { base[j] = 0ull; clen[j] = 0u; }
-                const uint32_t dir = flg[j] & 1u;
-                const uint32_t li = j * kThreads + tid;
-                s_off[li] = off[j] < B.n_blk ? off[j] : B.n_blk;
-                s_fbase[li] = counted ? (base[j] | (dir ? kFragDir : 0ull) | kFragValid) : 0ull;
-                s_fclen[li] = clen[j];
+                const uint32_t dir = (vflg >> (8 * j)) & 1u;
+                const uint32_t li = tid * kVec + j;
+                S.off[li] = in[j] ? (off[j] < B.n_blk ? off[j] : B.n_blk) : B.n_blk;
+                S.fb[li] = counted ? ((uint32_t)(base[j] >> 6) | (dir ? kFragDir : 0u) | kFragValid) : 0u;
+                S.fclen[li] = clen[j];
                 key[j] = counted ? chr[j] * 2u + dir : kEmpty;
             }
             if (tid == 0) {
                 // the window starts at the chunk's first fragment (coordinate-sorted input: the leftmost one)
                 unsigned long long w = 0;
                 if (key[0] != kEmpty && fs[0] <= clen[0]) {
-                    const uint64_t g = base[0] + fs[0];
-                    w = plane_of(T, T.pmap ? T.bkt[g >> kBucketShift].x : 0u, g) & ~63ull;
+                    const uint64_t gp = base[0] + fs[0];
+                    w = plane_of(T, T.pmap ? T.pmap[gp >> kBucketShift] : 0u, gp) & ~63ull;
                 }
-                s_win = w;
+                S.win = w;
             }
             // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
             if (!(T.ablate & 4u) && T.n_roi_dev) {
-                uint32_t r[kFragsPerThread];
-                bool extent_ok[kFragsPerThread];
+                uint32_t r[kVec];
+                bool extent_ok[kVec];
 #pragma unroll
-                for (int j = 0; j < kFragsPerThread; j++) {
+                for (int j = 0; j < kVec; j++) {
                     extent_ok[j] = key[j] != kEmpty && fs[j] <= fe[j] && fe[j] <= clen[j];
                     r[j] = T.roi_bucket[extent_ok[j] ? (base[j] + fe[j]) >> kBucketShift : 0ull];
                 }
-                uint64_t rge[kFragsPerThread], rgs[kFragsPerThread];
+                uint64_t rge[kVec], rgs[kVec];
 #pragma unroll
-                for (int j = 0; j < kFragsPerThread; j++) {
+                for (int j = 0; j < kVec; j++) {
                     if (r[j] >= T.n_roi_dev) { extent_ok[j] = false; r[j] = 0u; }
                     rge[j] = T.roi_gend[r[j]];
                     rgs[j] = T.roi_gstart[r[j]];
                 }
 #pragma unroll
-                for (int j = 0; j < kFragsPerThread; j++) {
+                for (int j = 0; j < kVec; j++) {
                     if (!extent_ok[j]) continue;
                     const uint64_t gfs = base[j] + fs[j], gfe = base[j] + fe[j];
                     uint32_t q = r[j];
@@ -207,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
             // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
             if (!(T.ablate & 16u)) {
 #pragma unroll
-                for (int j = 0; j < kFragsPerThread; j++) {
+                for (int j = 0; j < kVec; j++) {
                     const uint32_t k = key[j];
                     uint64_t todo = __ballot(k != kEmpty);
                     while (todo) {
@@ -216,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
                         const uint64_t same = __ballot(k == lk);
                         if ((int)lane == lead) {
                             const uint32_t n = (uint32_t)__popcll(same);
-                            if (lk < (uint32_t)kChrBins) atomicAdd(&s_chr[lk], n);
+                            if (lk < (uint32_t)kChrBins) atomicAdd(&S.chr[lk], n);
                             else atomicAdd(&T.chr_cnt[lk], n);
                         }
                         todo &= ~same;
@@ -226,207 +268,271 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
         }
         __syncthreads();
 
-        // ---------------- 2. block-parallel ----------------
-        const uint32_t kb0 = s_off[0], kb1 = s_off[kChunk];
-        const unsigned long long win = s_win;
+        // ---------------- 2. block-parallel: 4 consecutive blocks per lane ----------------
+        const uint32_t kb0 = S.off[0], kb1 = S.off[kChunk];
+        const unsigned long long win = S.win;
+        const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
+        const bool fold_ok = T.plane_stride <= 0xffffffffull;       // the junction cache keeps plane positions as uint32
         uint32_t wmax = 0;
-        for (uint32_t kk = kb0; kk < kb1 && !(T.ablate & 32u); kk += kThreads * kUnroll) {
-            uint32_t k[kUnroll], bs[kUnroll], bl[kUnroll], rd[kUnroll], bs2[kUnroll], bl2[kUnroll], rd2[kUnroll];
-            bool act[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                k[u] = kk + u * kThreads + tid;
-                act[u] = k[u] < kb1;
-                const bool nx = k[u] + 1u < kb1;
-                const uint32_t kc = act[u] ? k[u] : kb1 - 1u, kn = nx ? k[u] + 1u : kb1 - 1u;     // kb1 <= n_blk
-                bs[u] = B.blk_start[kc];
-                bl[u] = B.blk_len[kc];
-                rd[u] = B.blk_read[kc];
-                bs2[u] = B.blk_start[kn];
-                bl2[u] = B.blk_len[kn];
-                rd2[u] = nx ? (uint32_t)B.blk_read[kn] : 0xffu;
+        const uint32_t g_lastb = B.n_blk ? (B.n_blk - 1u) >> 2 : 0u;
+        for (uint32_t ka = kb0 & ~3u; ka < kb1 && !(T.ablate & 32u); ka += kThreads * kVec) {
+            const uint32_t k0 = ka + tid * kVec;
+            uint32_t bs[kVec + 1], bl[kVec + 1], rd[kVec + 1];
+            {
+                const uint32_t g = (k0 >> 2) < g_lastb ? (k0 >> 2) : g_lastb;
+                const uint4 vbs = bs4[g], vbl = bl4[g];
+                const uint32_t vrd = rd4[g];
+                // the block after the lane's four: the next lane's first; for the last lane, one more (wave-uniform) load
+                const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane((int)k0, 63) + kVec;
+                const uint32_t kxc = kx < B.n_blk ? kx : (B.n_blk ? B.n_blk - 1u : 0u);
+                const uint32_t xbs = B.blk_start[kxc], xbl = B.blk_len[kxc], xrd = B.blk_read[kxc];
+                bs[0] = vbs.x; bs[1] = vbs.y; bs[2] = vbs.z; bs[3] = vbs.w;
+                bl[0] = vbl.x; bl[1] = vbl.y; bl[2] = vbl.z; bl[3] = vbl.w;
+                rd[0] = vrd & 0xffu; rd[1] = (vrd >> 8) & 0xffu; rd[2] = (vrd >> 16) & 0xffu; rd[3] = vrd >> 24;
+                const uint32_t nbs = __shfl_down(bs[0], 1), nbl = __shfl_down(bl[0], 1), nrd = __shfl_down(rd[0], 1);
+                bs[4] = lane == 63u ? xbs : nbs;
+                bl[4] = lane == 63u ? xbl : nbl;
+                rd[4] = lane == 63u ? xrd : nrd;
             }
             // owner = the last fragment of the chunk whose offset is <= k (empty fragments share an offset with
-            // their successor and are never picked)
-            unsigned long long fb[kUnroll];
-            uint32_t clen[kUnroll];
-            bool next_same[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
+            // their successor and are never picked): binary search for the first block, a short walk for the others
+            uint32_t fbv[kVec], clen[kVec];
+            bool act[kVec], first[kVec], next_same[kVec];
+            {
                 uint32_t lo = 0, hi = kChunk;
-                if (T.ablate & 64u) { lo = (k[u] - kb0) / 3u; lo = lo < (uint32_t)kChunk ? lo : kChunk - 1; hi = lo; }
+                const uint32_t kq = k0 < kb0 ? kb0 : k0;
 #pragma unroll
                 for (int s = 0; s < kChunkLog2; s++) {
-                    if (T.ablate & 64u) break;
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (s_off[mid] <= k[u]) lo = mid; else hi = mid;
+                    if (S.off[mid] <= kq) lo = mid; else hi = mid;
                 }
-                fb[u] = act[u] ? s_fbase[lo] : 0ull;
-                clen[u] = s_fclen[lo];
-                next_same[u] = k[u] + 1u < s_off[lo + 1];
-            }
-            uint4 ea[kUnroll], eb[kUnroll];
-            uint64_t gbs[kUnroll], gbe[kUnroll];
-            bool ok[kUnroll];
+                uint32_t f = lo;
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                const uint32_t be = bs[u] + bl[u];
-                const bool valid = (fb[u] & kFragValid) != 0ull;
-                const bool in_range = be >= bs[u] && be <= clen[u];
+                for (int j = 0; j < kVec; j++) {
+                    const uint32_t k = k0 + j;
+                    act[j] = k >= kb0 && k < kb1;
+                    if (act[j]) { while (S.off[f + 1] <= k) f++; }        // off[kChunk] = kb1 > k ends the walk
+                    fbv[j] = act[j] ? S.fb[f] : 0u;
+                    clen[j] = S.fclen[f];
+                    first[j] = k == S.off[f];
+                    next_same[j] = k + 1u < S.off[f + 1];
+                }
+            }
+            // per block: validity, full coordinates, bucket-table entries of the start and of the end
+            bool ok[kVec + 1];
+            uint64_t gbs[kVec + 1], gbe[kVec];
+            uint2 es[kVec + 1];
+            uint4 ee[kVec];
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                const uint32_t be = bs[j] + bl[j];
+                const bool valid = (fbv[j] & kFragValid) != 0u;
+                const bool in_range = be >= bs[j] && be <= clen[j];
                 if (valid && !in_range) err |= ERR_BLOCK_RANGE;
-                ok[u] = valid && in_range;
-                const uint64_t base = fb[u] & kFragBaseMask;
-                gbs[u] = base + bs[u];
-                gbe[u] = base + be;
-                ea[u] = T.bkt[ok[u] ? gbs[u] >> kBucketShift : 0ull];
-                eb[u] = T.bkt[ok[u] ? gbe[u] >> kBucketShift : 0ull];
+                ok[j] = valid && in_range;
+                const uint64_t base = (uint64_t)(fbv[j] & kFragBaseMask) << 6;
+                gbs[j] = base + bs[j];
+                gbe[j] = base + be;
             }
+            {   // the successor of the lane's last block: same fragment (next_same[3]) or unused
+                const uint32_t be = bs[kVec] + bl[kVec];
+                ok[kVec] = ok[kVec - 1] && next_same[kVec - 1] && be >= bs[kVec] && be <= clen[kVec - 1];
+                gbs[kVec] = ((uint64_t)(fbv[kVec - 1] & kFragBaseMask) << 6) + bs[kVec];
+            }
+#pragma unroll
+            for (int j = 0; j <= kVec; j++) {
+                const uint4* e = T.bkt + (ok[j] ? gbs[j] >> kBucketShift : 0ull);
+                es[j] = *reinterpret_cast<const uint2*>(e);
+            }
+#pragma unroll
+            for (int j = 0; j < kVec; j++) ee[j] = T.bkt[ok[j] ? gbe[j] >> kBucketShift : 0ull];
             // junction to the right of the block: both flanks long enough, same read, same fragment
-            bool jc[kUnroll];
-            uint64_t jkey[kUnroll], kfirst[kUnroll];
+            bool jc[kVec];
+            uint64_t jkey[kVec], kfirst[kVec];
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                jc[u] = ok[u] && next_same[u] && rd2[u] == rd[u] && bl[u] >= T.junc_min_flank && bl2[u] >= T.junc_min_flank &&
+            for (int j = 0; j < kVec; j++) {
+                jc[j] = ok[j] && ok[j + 1] && next_same[j] && rd[j + 1] == rd[j] && bl[j] >= T.junc_min_flank && bl[j + 1] >= T.junc_min_flank &&
                         !(T.ablate & 8u);
-                const uint32_t be = bs[u] + bl[u];
-                const uint32_t span = bs2[u] - be;
-                if (jc[u] && (bs2[u] < be || span >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[u] = false; }
-                jkey[u] = (gbe[u] << kJuncSpanBits) | span;
-                const bool kq = jc[u] && (eb[u].w >> 16);
-                kfirst[u] = T.known_keys[kq ? eb[u].z : 0u];                  // the table holds at least one entry
-                if (!kq) kfirst[u] = ~0ull;
+                const uint32_t be = bs[j] + bl[j];
+                const uint32_t span = bs[j + 1] - be;
+                if (jc[j] && (bs[j + 1] < be || span >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[j] = false; }
+                jkey[j] = (gbe[j] << kJuncSpanBits) | span;
+                const bool kq = jc[j] && (ee[j].w >> 16);
+                kfirst[j] = T.known_keys[kq ? ee[j].z : 0u];                  // the table holds at least one entry
+                if (!kq) kfirst[j] = ~0ull;
             }
+            // known junction?  (index into known_keys, or kEmpty)
+            uint32_t hit[kVec];
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                if (!ok[u]) continue;
-                const uint32_t dir = (fb[u] & kFragDir) ? 1u : 0u;
-                if (bl[u] > 0u) {
-                    if (!(T.ablate & 1u)) {
-                        // CoverageBlocks / FragmentsMap: difference events, LDS window first
-                        const uint64_t cs = plane_of(T, ea[u].x, gbs[u]), ce = plane_of(T, eb[u].x, gbe[u]);
-                        const uint64_t os = cs - win, oe = ce - win;
-                        int32_t* tile = s_tile + dir * kWin;
-                        if (os < kWin) { atomicAdd(&tile[os], 1); wmax = (uint32_t)os > wmax ? (uint32_t)os : wmax; }
-                        else far_event(T, s_etag, s_ecnt, cs, dir, 1);
-                        if (oe < kWin) { atomicAdd(&tile[oe], -1); wmax = (uint32_t)oe > wmax ? (uint32_t)oe : wmax; }
-                        else far_event(T, s_etag, s_ecnt, ce, dir, -1);
-                    }
-                    // SpansPoint: the points of the buckets under the block, filtered to [lo, hi]
-                    if (bl[u] > T.sp_min_len && !(T.ablate & 2u)) {
-                        uint32_t p = ea[u].y;
-                        const uint32_t pn = eb[u].w & 0xffffu;
-                        const uint32_t p1 = pn == 0xffffu ? T.bkt[(gbe[u] >> kBucketShift) + 1u].y : eb[u].y + pn;
-                        if (p < p1) {
-                            const uint64_t lo = gbs[u] + T.sp_lo_add, hi = gbe[u] - T.sp_hi_sub;
-                            uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
-                            for (; p < p1; p++) {
-                                const uint64_t g = T.sp_gpos[p];
-                                if (g > hi) break;
-                                if (g >= lo) atomicAdd(&sp_cnt[T.sp_row[p]], 1u);
-                            }
+            for (int j = 0; j < kVec; j++) {
+                hit[j] = kEmpty;
+                const uint32_t kn = ee[j].w >> 16;
+                if (jc[j] && kn) {
+                    const uint32_t i0 = ee[j].z;
+                    if (kfirst[j] >= jkey[j]) {
+                        if (kfirst[j] == jkey[j]) hit[j] = i0;
+                    } else {
+                        uint32_t lo = i0 + 1u;
+                        uint32_t hi = kn == 0xffffu ? T.bkt[(gbe[j] >> kBucketShift) + 1u].z : i0 + kn;
+                        while (hi - lo > 4u) {        // many junctions share this donor bucket: bisect first
+                            const uint32_t mid = lo + ((hi - lo) >> 1);
+                            if (T.known_keys[mid] < jkey[j]) lo = mid + 1u; else hi = mid + 1u;
+                        }
+                        for (; lo < hi; lo++) {
+                            const uint64_t kq = T.known_keys[lo];
+                            if (kq >= jkey[j]) { if (kq == jkey[j]) hit[j] = lo; break; }
                         }
                     }
                 }
-                if (jc[u]) {
-                    // JunctionCount: known junction -> its counter (through the per-chunk LDS cache); else a novel event
-                    int64_t hit = -1;
-                    const uint32_t kn = eb[u].w >> 16;
-                    if (kn) {
-                        const uint32_t i0 = eb[u].z;
-                        if (kfirst[u] >= jkey[u]) {
-                            if (kfirst[u] == jkey[u]) hit = i0;
-                        } else {
-                            uint32_t lo = i0 + 1u;
-                            uint32_t hi = kn == 0xffffu ? T.bkt[(gbe[u] >> kBucketShift) + 1u].z : i0 + kn;
-                            while (hi - lo > 4u) {        // many junctions share this donor bucket: bisect first
-                                const uint32_t mid = lo + ((hi - lo) >> 1);
-                                if (T.known_keys[mid] < jkey[u]) lo = mid + 1u; else hi = mid + 1u;
-                            }
-                            for (; lo < hi; lo++) {
-                                const uint64_t kq = T.known_keys[lo];
-                                if (kq >= jkey[u]) { if (kq == jkey[u]) hit = lo; break; }
-                            }
-                        }
+            }
+            // JunctionCount on known junctions: the junction's LDS counter (same-address LDS atomics of a wave are
+            // serialised by the hardware at about a lane per clock: cheaper than electing leaders in software).
+            // folded = the junction's counter now also stands for this read's two difference events
+            bool folded[kVec];
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                folded[j] = false;
+                if (hit[j] != kEmpty) {
+                    folded[j] = junction_add(T, S, hit[j], (fbv[j] & kFragDir) ? 1u : 0u, 1u, plane_of(T, ee[j].x, gbe[j]),
+                                             plane_of(T, es[j + 1].x, gbs[j + 1])) && fold_ok;
+                }
+            }
+            // difference events, SpansPoint, novel junctions
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                if (!ok[j]) continue;
+                const uint32_t dir = (fbv[j] & kFragDir) ? 1u : 0u;
+                if (!(T.ablate & 1u)) {
+                    // CoverageBlocks / FragmentsMap.  A block emits its own end and its successor's start (unless a
+                    // known junction's counter stands for both); a fragment's first block also emits its own start.
+                    if (first[j]) depth_event(T, S, win, use_win, plane_of(T, es[j].x, gbs[j]), dir, 1, wmax);
+                    if (!folded[j]) {
+                        depth_event(T, S, win, use_win, plane_of(T, ee[j].x, gbe[j]), dir, -1, wmax);
+                        if (next_same[j] && ok[j + 1]) depth_event(T, S, win, use_win, plane_of(T, es[j + 1].x, gbs[j + 1]), dir, 1, wmax);
                     }
-                    if (hit >= 0) {
-                        const uint32_t idx = (uint32_t)hit, cslot = idx & (kJCache - 1);
-                        uint32_t tag = s_jtag[cslot];
-                        if (tag == kEmpty) { const uint32_t old = atomicCAS(&s_jtag[cslot], kEmpty, idx); tag = old == kEmpty ? idx : old; }
-                        if (tag == idx) atomicAdd(&s_jcnt[dir][cslot], 1u);
-                        else atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + T.known_kjidx[idx]], 1u);
-                    } else {
-                        const uint64_t ev = (gbe[u] << kJuncLeftShift) | ((jkey[u] & ((1ull << kJuncSpanBits) - 1ull)) << 1) | dir;
-                        const uint32_t q = atomicAdd(&s_nq_n, 1u);
-                        if (q < kNovelQ) {
-                            s_nq[q] = ev;
-                        } else {
-                            // queue full (a run without ref-sj.ref): the lanes that got here reserve slots together
-                            const uint64_t m = __ballot(1);
-                            unsigned long long b = 0;
-                            if ((int)lane == __ffsll((long long)m) - 1) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
-                            b = __shfl(b, __ffsll((long long)m) - 1);
-                            const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                            if (slot < T.junc_capacity) T.junc_keys[slot] = ev; else err |= ERR_JUNC_CAPACITY;
+                }
+                // SpansPoint: the points of the buckets under the block, filtered to [lo, hi]; four points per round
+                // trip (the first ones usually are the block's own exon boundaries, just outside [lo, hi])
+                if (bl[j] > T.sp_min_len && !(T.ablate & 2u)) {
+                    uint32_t p = es[j].y;
+                    const uint32_t pn = ee[j].w & 0xffffu;
+                    const uint32_t p1 = pn == 0xffffu ? T.bkt[(gbe[j] >> kBucketShift) + 1u].y : ee[j].y + pn;
+                    const uint64_t lo = gbs[j] + T.sp_lo_add, hi = gbe[j] - T.sp_hi_sub;
+                    uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
+                    while (p < p1) {
+                        uint64_t gp[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) gp[q] = T.sp_gpos[p + q < p1 ? p + q : p1 - 1u];
+                        bool done = false;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            if (p + q < p1 && !done) {
+                                if (gp[q] > hi) done = true;
+                                else if (gp[q] >= lo) {
+                                    const uint32_t pi = p + q, slot = pi & (kPCache - 1u);
+                                    uint32_t tag = S.ptag[slot];
+                                    if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ptag[slot], kEmpty, pi); tag = old == kEmpty ? pi : old; }
+                                    if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
+                                    else atomicAdd(&sp_cnt[T.sp_row[pi]], 1u);
+                                }
+                            }
                         }
+                        if (done) break;
+                        p += 4u;
+                    }
+                }
+                if (jc[j] && hit[j] == kEmpty) {
+                    // novel junction: a packed event for the sort-reduce at finalize
+                    const uint64_t ev = (gbe[j] << kJuncLeftShift) | ((jkey[j] & ((1ull << kJuncSpanBits) - 1ull)) << 1) | dir;
+                    const uint32_t q = atomicAdd(&S.nq_n, 1u);
+                    if (q < kNovelQ) {
+                        S.nq[q] = ev;
+                    } else {
+                        // queue full (a run without ref-sj.ref): the lanes that got here reserve slots together
+                        const uint64_t m = __ballot(1);
+                        const int lead = __ffsll((long long)m) - 1;
+                        unsigned long long b = 0;
+                        if ((int)lane == lead) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
+                        b = __shfl(b, lead);
+                        const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < T.junc_capacity) T.junc_keys[slot] = ev; else err |= ERR_JUNC_CAPACITY;
                     }
                 }
             }
         }
-        if (wmax) atomicMax(&s_wmax, wmax);
         __syncthreads();
 
         // ---------------- 3. flush the LDS accumulators ----------------
-        const uint32_t nq = s_nq_n < kNovelQ ? s_nq_n : kNovelQ;
-        const uint32_t wtop = s_wmax;
-        if (tid == 0 && nq) s_nq_base = atomicAdd(T.junc_count, (unsigned long long)nq);
-        for (uint32_t e = tid; e < kECache; e += kThreads) {
-            const uint32_t tag = s_etag[e];
-            if (tag != kEmpty) {
-                const int32_t v = s_ecnt[e];
-                const uint64_t gd = ((uint64_t)tag << kECacheBits) | e;
-                if (v) __hip_atomic_fetch_add(T.diff + (gd & 1u) * T.plane_stride + (gd >> 1), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_etag[e] = kEmpty; s_ecnt[e] = 0;
-            }
-        }
+        // 3a. the junction cache: counters to the table, the junctions' difference events into window / line cache
+        const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ;
+        if (tid == 0 && nq) S.nq_base = atomicAdd(T.junc_count, (unsigned long long)nq);
         for (uint32_t e = tid; e < kJCache; e += kThreads) {
-            const uint32_t idx = s_jtag[e];
+            const uint32_t idx = S.jtag[e];
             if (idx != kEmpty) {
-                const uint32_t c0 = s_jcnt[0][e], c1 = s_jcnt[1][e];
+                const uint32_t c0 = S.jcnt[0][e], c1 = S.jcnt[1][e];
                 const uint32_t row = T.known_kjidx[idx];
+                const uint2 pos = S.jpos[e];
+                if (!(T.ablate & 1u) && fold_ok) {
+                    if (c0) { depth_event(T, S, win, use_win, pos.x, 0u, -(int)c0, wmax); depth_event(T, S, win, use_win, pos.y, 0u, (int)c0, wmax); }
+                    if (c1) { depth_event(T, S, win, use_win, pos.x, 1u, -(int)c1, wmax); depth_event(T, S, win, use_win, pos.y, 1u, (int)c1, wmax); }
+                }
                 if (c0) atomicAdd(&T.known_cnt[row], c0);
                 if (c1) atomicAdd(&T.known_cnt[(uint64_t)T.n_kj + row], c1);
-                s_jtag[e] = kEmpty; s_jcnt[0][e] = 0; s_jcnt[1][e] = 0;
+                S.jtag[e] = kEmpty; S.jcnt[0][e] = 0; S.jcnt[1][e] = 0;
             }
         }
-        // the window, only as far as it was touched
-        for (uint32_t e = tid * 4u; e <= wtop; e += kThreads * 4u) {
-#pragma unroll
-            for (uint32_t d = 0; d < 2u; d++) {
-                int4* cell = reinterpret_cast<int4*>(&s_tile[d * kWin + e]);
-                const int4 v = *cell;
-                if (v.x | v.y | v.z | v.w) {
-                    int32_t* g = T.diff + (uint64_t)d * T.plane_stride + win + e;
-                    if (v.x) __hip_atomic_fetch_add(g + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v.y) __hip_atomic_fetch_add(g + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v.z) __hip_atomic_fetch_add(g + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v.w) __hip_atomic_fetch_add(g + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *cell = make_int4(0, 0, 0, 0);
+        for (uint32_t e = tid; e < kPCache; e += kThreads) {
+            const uint32_t pi = S.ptag[e];
+            if (pi != kEmpty) {
+                const uint32_t c0 = S.pcnt[0][e], c1 = S.pcnt[1][e];
+                const uint32_t row = T.sp_row[pi];
+                if (c0) atomicAdd(&T.sp_cnt[row], c0);
+                if (c1) atomicAdd(&T.sp_cnt[(uint64_t)T.n_sp + row], c1);
+                S.ptag[e] = kEmpty; S.pcnt[0][e] = 0; S.pcnt[1][e] = 0;
+            }
+        }
+        if (wmax) atomicMax(&S.wmax, wmax);
+        __syncthreads();
+        // 3b. line cache and window: consecutive lanes = consecutive positions, so that a wave's atomics fall into
+        //     whole 64-byte lines (the memory-side atomic unit works per line)
+        const uint32_t wtop = S.wmax;
+        for (uint32_t e = tid; e < kLines * 16u; e += kThreads) {
+            const uint32_t slot = e >> 4, cell = e & 15u;
+            const uint32_t tag = S.ltag[slot];
+            if (tag != kEmpty) {
+                const int32_t v = S.lcnt[slot][cell];
+                if (v) {
+                    if (!(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + (uint64_t)(tag & 1u) * T.plane_stride + ((uint64_t)(tag >> 1) << 4) + cell, v,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    S.lcnt[slot][cell] = 0;
                 }
             }
         }
+        for (uint32_t e = tid; e <= wtop; e += kThreads) {
+            const int32_t v = S.tile[e];
+            if (v) {
+                const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
+                const int32_t v1 = (v - v0) >> 16;
+                int32_t* g = T.diff + win + e;
+                if (v0 && !(T.ablate & 256u)) __hip_atomic_fetch_add(g, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v1 && !(T.ablate & 256u)) __hip_atomic_fetch_add(g + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S.tile[e] = 0;
+            }
+        }
         __syncthreads();
-        if (tid == 0) { s_nq_n = 0; s_wmax = 0; }
+        for (uint32_t e = tid; e < kLines; e += kThreads) S.ltag[e] = kEmpty;
+        if (tid == 0) { S.nq_n = 0; S.wmax = 0; }
         if (nq) {
-            const unsigned long long qb = s_nq_base;
+            const unsigned long long qb = S.nq_base;
             for (uint32_t e = tid; e < nq; e += kThreads) {
-                if (qb + e < T.junc_capacity) T.junc_keys[qb + e] = s_nq[e]; else err |= ERR_JUNC_CAPACITY;
+                if (qb + e < T.junc_capacity) T.junc_keys[qb + e] = S.nq[e]; else err |= ERR_JUNC_CAPACITY;
             }
         }
     }
     if (err) atomicOr(T.err_flags, err);
     __syncthreads();
     for (int k = tid; k < kChrBins; k += kThreads) {
-        const uint32_t v = s_chr[k];
+        const uint32_t v = S.chr[k];
         if (v && (uint32_t)(k >> 1) < T.n_chr) atomicAdd(&T.chr_cnt[k], v);
     }
 }
@@ -435,9 +541,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(CountTables T, BatchDev
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;
-    // 70 KB of LDS per workgroup: two workgroups per CU, 256 CUs; a multiple of 8 for the XCD mapping
     const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
-    uint32_t blocks = ((n_chunks + 7u) / 8u) * 8u;
+    uint32_t blocks = ((n_chunks + 7u) / 8u) * 8u;            // a multiple of 8 for the XCD mapping
     if (blocks > 256u * K_WGS_PER_CU) blocks = 256u * K_WGS_PER_CU;
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, T, B);
 }

@@ -604,6 +604,11 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
     B.n_frag = b->n_frag; B.n_blk = b->n_blk;
     Staging* st = nullptr;
     if (b->mem_kind == IRF_MEM_DEVICE) {
+        // the count kernel reads the columns with 16-byte (uint32 columns) and 4-byte (uint8 columns) vector loads
+        auto mis = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; };
+        if (mis(b->frag_chr, 16) || mis(b->frag_start, 16) || mis(b->frag_end, 16) || mis(b->frag_blk_off, 16) || mis(b->frag_flags, 4) ||
+            (b->n_blk && (mis(b->blk_start, 16) || mis(b->blk_len, 16) || mis(b->blk_read, 4))))
+            return fail(IRF_E_ARG, "device-resident batch columns must be 16-byte aligned (uint32 columns) / 4-byte aligned (uint8 columns)");
         B.frag_chr = b->frag_chr; B.frag_flags = b->frag_flags; B.frag_start = b->frag_start; B.frag_end = b->frag_end;
         B.frag_blk_off = b->frag_blk_off; B.blk_start = b->blk_start; B.blk_len = b->blk_len; B.blk_read = b->blk_read;
     } else {
