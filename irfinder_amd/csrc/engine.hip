@@ -88,7 +88,6 @@ struct irf_ctx {
     uint64_t full_size = 0;                      // full coordinate space: sum of owned (len+1, rounded to 64)
     std::vector<uint32_t> pmap;                  // full -> plane, per 512-bucket; empty = identity
     DevBuf<uint32_t> d_pmap;
-    DevBuf<uint64_t> d_blk_cstart;
 
     // ---- device state ----
     DevBuf<int32_t> d_diff;
@@ -112,14 +111,12 @@ struct irf_ctx {
     uint64_t n_unique = 0, n_events = 0;
     const uint64_t* d_sorted = nullptr;
     // intron tables
-    DevBuf<uint8_t> d_in_valid, d_in_plus;
-    DevBuf<uint64_t> d_in_gstart, d_in_gend, d_blk_gstart, d_in_measured;
-    DevBuf<uint32_t> d_in_blk_off, d_blk_len;
-    DevBuf<int32_t> d_sp_idx_s, d_sp_idx_e, d_us_idx, d_ue_idx;
+    DevBuf<dev::IntronRec> d_in_recs;              // one record per intron, in launch order (size classes)
+    DevBuf<dev::BlkRec> d_blk_recs;
+    dev::StatsClasses stats_classes;
     DevBuf<uint64_t> d_us_pos, d_ue_pos, d_known_keys;
     DevBuf<uint8_t> d_known_dir;
     DevBuf<uint32_t> d_known_kjidx, d_known_cnt;   // known-junction rows and their [2][n_kj] counters
-    DevBuf<int32_t> d_kj_idx;                      // per intron: row of (Start,End) in the known table, -1 if none
     uint32_t n_kj = 0;
     unsigned long long votes[2] = {0, 0};
     uint64_t n_junction_events_total = 0;
@@ -199,6 +196,12 @@ int alloc_zero(irf_ctx* c, DevBuf<T>& buf, size_t n) {
 }
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+
+// tuning knob read from the environment (diagnostic; the defaults are the shipped configuration)
+uint64_t env_u64(const char* name, uint64_t dflt) {
+    const char* v = getenv(name);
+    return v && *v ? strtoull(v, nullptr, 10) : dflt;
+}
 
 }   // namespace
 
@@ -494,13 +497,40 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             uei[i] = (int32_t)(std::lower_bound(ue.begin(), ue.end(), ge[i]) - ue.begin());
         }
         n_us = (uint32_t)us.size(); n_ue = (uint32_t)ue.size();
-        TRY(upload(this, d_in_valid, valid)); TRY(upload(this, d_in_plus, plus));
-        TRY(upload(this, d_in_gstart, gs)); TRY(upload(this, d_in_gend, ge));
-        TRY(upload(this, d_in_blk_off, ref.in_blk_off));
-        TRY(upload(this, d_blk_gstart, bgs)); TRY(upload(this, d_blk_cstart, bcs)); TRY(upload(this, d_blk_len, bl));
-        TRY(upload(this, d_in_measured, ref.in_measured));
-        TRY(upload(this, d_sp_idx_s, sis)); TRY(upload(this, d_sp_idx_e, sie));
-        TRY(upload(this, d_us_idx, usi)); TRY(upload(this, d_ue_idx, uei)); TRY(upload(this, d_kj_idx, kji));
+        // one record per intron, sorted into the size classes of the statistics kernel (kernels.h: StatsClasses),
+        // longest first inside a class so that the long ones do not trail the launch
+        {
+            const uint64_t small_max = P.flank_len <= dev::kStatsSmallFlank ? env_u64("IRF_STATS_SMALL_MAX", dev::kStatsSmallMax) : 0ull;
+            const uint64_t huge_min = env_u64("IRF_STATS_HUGE_MIN", dev::kStatsHugeMin);
+            auto cls = [&](uint32_t i) -> int {
+                const uint64_t m = ref.in_measured[i];
+                return m >= huge_min ? 0 : (m <= small_max ? 2 : 1);
+            };
+            std::vector<uint32_t> order(n_intron);
+            for (uint32_t i = 0; i < n_intron; i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                const int ca = cls(a), cb = cls(b);
+                if (ca != cb) return ca < cb;
+                return ref.in_measured[a] > ref.in_measured[b];
+            });
+            std::vector<dev::IntronRec> recs(n_intron);
+            memset(&stats_classes, 0, sizeof stats_classes);
+            for (uint32_t k = 0; k < n_intron; k++) {
+                const uint32_t i = order[k];
+                dev::IntronRec& r = recs[k];
+                memset(&r, 0, sizeof r);
+                r.g_start = gs[i]; r.g_end = ge[i]; r.measured = ref.in_measured[i];
+                r.blk_off = ref.in_blk_off[i]; r.n_blk = ref.in_blk_off[i + 1] - ref.in_blk_off[i];
+                r.sp_s = sis[i]; r.sp_e = sie[i]; r.us = usi[i]; r.ue = uei[i]; r.kj = kji[i];
+                r.row = i; r.valid = valid[i]; r.plus = plus[i];
+                const int c = cls(i);
+                if (stats_classes.count[c]++ == 0) stats_classes.first[c] = k;
+            }
+            std::vector<dev::BlkRec> blks(ref.blk_start.size());
+            for (size_t b = 0; b < blks.size(); b++) { blks[b].gstart = bgs[b]; blks[b].cstart = bcs[b]; blks[b].len = bl[b]; blks[b].pad = 0; }
+            if (blks.empty()) blks.resize(1);          // the kernel's clamped descriptor load needs one entry
+            TRY(upload(this, d_in_recs, recs)); TRY(upload(this, d_blk_recs, blks));
+        }
         TRY(upload(this, d_us_pos, us)); TRY(upload(this, d_ue_pos, ue));
         TRY(alloc_zero(this, d_left_cnt, (size_t)n_us * 2));
         TRY(alloc_zero(this, d_right_cnt, (size_t)n_ue * 2));
@@ -670,13 +700,11 @@ void irf_ctx::launch_stats(int t, int dirn) {
     dev::IntronTables T;
     memset(&T, 0, sizeof T);
     T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
-    T.valid = d_in_valid.p; T.strand_plus = d_in_plus.p; T.g_start = d_in_gstart.p; T.g_end = d_in_gend.p;
-    T.blk_off = d_in_blk_off.p; T.blk_gstart = d_blk_gstart.p; T.blk_cstart = d_blk_cstart.p; T.pmap = pmap.empty() ? nullptr : d_pmap.p; T.blk_len = d_blk_len.p; T.measured = d_in_measured.p;
-    T.sp_idx_start = d_sp_idx_s.p; T.sp_idx_end = d_sp_idx_e.p; T.sp_cnt = d_sp_cnt.p;
-    T.us_idx = d_us_idx.p; T.ue_idx = d_ue_idx.p; T.left_cnt = d_left_cnt.p; T.right_cnt = d_right_cnt.p;
+    T.recs = d_in_recs.p; T.blks = d_blk_recs.p; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
+    T.sp_cnt = d_sp_cnt.p; T.left_cnt = d_left_cnt.p; T.right_cnt = d_right_cnt.p;
     T.n_ustart = n_us; T.n_uend = n_ue;
     T.ukeys = d_ukeys.p; T.ucount = d_ucount.p; T.n_unique = n_unique;
-    T.kj_idx = d_kj_idx.p; T.known_cnt = d_known_cnt.p; T.n_kj = n_kj;
+    T.known_cnt = d_known_cnt.p; T.n_kj = n_kj;
     { const char* ab = getenv("IRF_ABLATE_STATS"); T.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
     T.trim_centre_pct = P.trim_centre_pct; T.pct_interpolate = P.pct_interpolate;
     T.flank_offset = P.flank_offset; T.flank_len = P.flank_len; T.flank_use_measured = P.flank_use_measured;
@@ -685,7 +713,7 @@ void irf_ctx::launch_stats(int t, int dirn) {
     T.warn_minor_ratio = P.warn_minor_ratio; T.warn_nonuniform_rel = P.warn_nonuniform_rel;
     T.warn_nonuniform_abs = P.warn_nonuniform_abs;
     T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
-    dev::launch_intron_stats(T, stream);
+    dev::launch_intron_stats(T, stats_classes, stream);
 }
 
 int irf_ctx::finalize() {

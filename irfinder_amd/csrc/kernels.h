@@ -147,34 +147,50 @@ void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s);
 void launch_known_lookups(const JuncLookupTables& J, hipStream_t s);
 
 // ---- per-intron statistics + IR table --------------------------------------------
+// Everything a row needs besides depth, one 64-byte record per intron (the kernel reads it with scalar loads).
+struct IntronRec {
+    uint64_t g_start, g_end;       // full coordinates of the intron
+    uint64_t measured;             // sum of the measured block lengths
+    uint32_t blk_off, n_blk;       // measured blocks: blks[blk_off .. blk_off + n_blk)
+    int32_t sp_s, sp_e;            // index into sp_cnt of the point at Start / End (-1: none)
+    int32_t us, ue;                // index into left_cnt / right_cnt
+    int32_t kj;                    // row of the known-junction table for (Start,End), -1 if not in ref-sj
+    uint32_t row;                  // row of the IR table (= record index in ref-cover.bed)
+    uint8_t valid;                 // chromosome present in the BAM header and owned
+    uint8_t plus;                  // 1 unless strand == '-'
+    uint8_t pad[2];
+};
+static_assert(sizeof(IntronRec) == 64, "IntronRec is one 64-byte line");
+struct BlkRec {                    // one measured block
+    uint64_t gstart;               // full coordinates
+    uint64_t cstart;               // plane (compact) coordinates
+    uint32_t len;
+    uint32_t pad;
+};
+// recs is sorted into size classes (by measured bases), longest first inside a class: class c = records
+// [first[c], first[c] + count[c]); 0 = huge (1024-thread workgroups), 1 = 256 threads, 2 = small (64 threads)
+struct StatsClasses { uint32_t first[3], count[3]; };
+constexpr uint32_t kStatsMaxFlank = 512;       // flank_len limit (LDS window buffers)
+constexpr uint32_t kStatsSmallFlank = 64;      // ... of the 64-thread class
+constexpr uint64_t kStatsSmallMax = 2048;      // class 2: measured <= this
+constexpr uint64_t kStatsHugeMin = 65536;      // class 0: measured >= this
+
 struct IntronTables {
     uint32_t n_intron;
     uint32_t n_sp;
     uint64_t plane_stride;
     const int32_t* diff;           // [2][plane_stride] difference events (NOT scanned)
     const uint32_t* carry;         // [2][plane_stride/256] depth just before each 256-position segment
-    const uint8_t* valid;          // [n_intron] chromosome present in the BAM header and owned
-    const uint8_t* strand_plus;    // [n_intron] 1 unless strand == '-'
-    const uint64_t* g_start;       // global start / end of the intron
-    const uint64_t* g_end;
-    const uint32_t* blk_off;       // [n_intron+1]
-    const uint64_t* blk_gstart;    // measured blocks, full coordinates
-    const uint64_t* blk_cstart;    // ... and their plane (compact) coordinates
+    const IntronRec* recs;         // [n_intron] in launch order
+    const BlkRec* blks;
     const uint32_t* pmap;          // full -> plane map (nullptr = identity), for raw-coordinate flank windows
-    const uint32_t* blk_len;
-    const uint64_t* measured;      // [n_intron]
-    const int32_t* sp_idx_start;   // index into sp_cnt of the point at Start (-1: none)
-    const int32_t* sp_idx_end;
     const uint32_t* sp_cnt;        // [2][n_sp]
-    const int32_t* us_idx;         // index into left_cnt
-    const int32_t* ue_idx;
-    const uint32_t* left_cnt;
-    const uint32_t* right_cnt;
+    const uint32_t* left_cnt;      // [2][n_ustart]
+    const uint32_t* right_cnt;     // [2][n_uend]
     uint32_t n_ustart, n_uend;
     const uint64_t* ukeys;         // novel unique junctions
     const uint32_t* ucount;
     uint64_t n_unique;
-    const int32_t* kj_idx;         // [n_intron] row of the known-junction table for (Start,End), -1 if not in ref-sj
     const uint32_t* known_cnt;     // [2][n_kj]
     uint32_t n_kj;
     uint32_t ablate;               // diagnostic only (IRF_ABLATE_STATS): bit0 no depth pass, bit1 no row tail
@@ -187,7 +203,7 @@ struct IntronTables {
     uint32_t* out_u32;             // [6][n_intron]  (5 counts + warning)
     uint32_t* err_flags;
 };
-void launch_intron_stats(const IntronTables& T, hipStream_t s);
+void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s);
 
 }   // namespace dev
 }   // namespace irf

@@ -21,10 +21,19 @@
 // segment as 64 x int4, one wave-wide prefix sum gives the 256 depths.  Both
 // strands (non-directional table) are summed BEFORE the prefix (it is linear).
 // HBM-bound: 4 B (one strand) or 8 B (both) per measured base, read once; the
-// first/last-50-nt windows are captured from the same pass.  Two segments are in
-// flight per wave; depth is piecewise constant, so a segment that holds one
-// value 256 times (most do) costs ONE LDS atomic, and mixed segments aggregate
-// equal values per wave before touching the histogram.
+// first/last-50-nt windows are captured from the same pass.
+//
+// Shape.  200 k introns of very different sizes (median 1.7 k measured bases, tail to 0.5 M): a short intron is
+// a chain of dependent round trips (record -> block descriptors -> planes), a long one is a stream.  So
+//   * the host sorts the introns into three size classes, longest first inside a class, and each class gets its own
+//     workgroup size (1024 / 256 / 64 threads): a CU holds 32 short introns at once instead of 8;
+//   * everything the row needs besides depth sits in ONE 64-byte record per intron (scalar loads), and the counters
+//     of the row's tail are fetched at the top, under the depth pass;
+//   * the measured blocks of an intron are flattened into one list of segments: lane b of every wave keeps the
+//     descriptor of block b in registers (no LDS, no barrier), a ballot finds the block of a segment, and a wave has
+//     kInFlight segments of loads outstanding before it touches the first;
+//   * depth is piecewise constant, so a segment that holds one value 256 times (most do) costs ONE LDS atomic, and
+//     mixed segments aggregate equal values per wave before touching the histogram.
 #include "kernels.h"
 
 namespace irf {
@@ -32,14 +41,11 @@ namespace dev {
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
 constexpr int kBinBits = 10;
 constexpr int kBins = 1 << kBinBits;
-constexpr int kBinsPerThread = kBins / kThreads;   // 4
-constexpr int kMaxFlank = 512;
 constexpr int kQueries = 8;
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
+constexpr uint32_t kMaxBlk = 64;    // measured blocks per descriptor chunk: one per lane
 
 struct Ctx {
     const int32_t* d0;              // difference planes
@@ -61,6 +67,13 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
     return (uint32_t)v;
+}
+
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, uint32_t src) {          // src is wave-uniform
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+}
+__device__ __forceinline__ uint64_t lane_u64(uint64_t v, uint32_t src) {
+    return (uint64_t)lane_u32((uint32_t)v, src) | ((uint64_t)lane_u32((uint32_t)(v >> 32), src) << 32);
 }
 
 __device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane) {
@@ -94,8 +107,8 @@ __device__ __forceinline__ void emit_seg(const Seg& s, uint64_t k, uint32_t lane
 
 // Depth of the PLANE positions of every 256-position segment that overlaps [gs, ge), spread over the workgroup: each
 // wave walks whole segments (so every DPP / ballot inside f runs with 64 active lanes), two segments in flight.
-// The callback clips to [gs, ge) itself.
-template <class F>
+// The callback clips to [gs, ge) itself.  (Side paths only: raw-coordinate windows, introns deeper than the histogram.)
+template <int kWaves, class F>
 __device__ __forceinline__ void for_each_segment(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
     if (gs >= ge) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -111,9 +124,9 @@ __device__ __forceinline__ void for_each_segment(const Ctx& C, uint64_t gs, uint
 }
 
 // per-position form: f(x, v, ok) for the four positions of every lane, ok = x in [gs, ge)
-template <class F>
+template <int kWaves, class F>
 __device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64_t ge, F&& f) {
-    for_each_segment(C, gs, ge, [&](uint64_t, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    for_each_segment<kWaves>(C, gs, ge, [&](uint64_t, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
         f(e0 + 0, v0, e0 + 0 >= gs && e0 + 0 < ge);
         f(e0 + 1, v1, e0 + 1 >= gs && e0 + 1 < ge);
         f(e0 + 2, v2, e0 + 2 >= gs && e0 + 2 < ge);
@@ -121,7 +134,8 @@ __device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64
     });
 }
 
-// Exclusive prefix over the 256 threads of (count, sum); s_w* are LDS scratch of kWaves entries.
+// Exclusive prefix over the threads of the workgroup of (count, sum); s_w* are LDS scratch of kWaves entries.
+template <int kWaves>
 __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long tsum, uint32_t& pre,
                                                 unsigned long long& pre_sum, uint32_t* s_wc, unsigned long long* s_ws) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -137,7 +151,6 @@ __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long
     __syncthreads();
     uint32_t bc = 0;
     unsigned long long bs = 0;
-#pragma unroll
     for (int w = 0; w < kWaves; w++)
         if (w < (int)wave) { bc += s_wc[w]; bs += s_ws[w]; }
     pre = bc + c - tot;
@@ -145,60 +158,82 @@ __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long
     __syncthreads();
 }
 
-// p-th percentile (OQ-7 formula) of n sorted values
-__device__ __forceinline__ double percentile_sorted(const uint32_t* sorted, uint32_t n, uint32_t pct, bool interpolate) {
-    if (n == 0) return 0.0;
-    const unsigned long long num = (unsigned long long)(n + 1u) * pct;
+// The two ranks (0-based) the p-th percentile of n sorted values reads (OQ-7 formula), and its value from them.
+struct PctRanks { unsigned long long ra, rb; uint32_t rem; bool need_a, need_b; };
+__device__ __forceinline__ PctRanks percentile_ranks(unsigned long long n, uint32_t pct, bool interpolate) {
+    PctRanks q;
+    q.ra = 0; q.rb = 0; q.need_a = n > 0; q.need_b = false;
+    const unsigned long long num = (n + 1ull) * pct;
     const unsigned long long k = num / 100ull;
-    const uint32_t rem = (uint32_t)(num % 100ull);
-    if (k < 1) return (double)sorted[0];
-    if (k >= n) return (double)sorted[n - 1];
-    const double vk = (double)sorted[k - 1];
-    if (!interpolate || rem == 0) return vk;
-    return vk + ((double)rem / 100.0) * ((double)sorted[k] - vk);
+    q.rem = (uint32_t)(num % 100ull);
+    if (n > 0) {
+        if (k < 1) q.ra = 0;
+        else if (k >= n) q.ra = n - 1;
+        else { q.ra = k - 1; q.rb = k; q.need_b = interpolate && q.rem != 0; }
+    }
+    return q;
+}
+__device__ __forceinline__ double percentile_value(const PctRanks& q, uint32_t va, uint32_t vb) {
+    if (!q.need_a) return 0.0;
+    const double vk = (double)va;
+    if (!q.need_b) return vk;
+    return vk + ((double)q.rem / 100.0) * ((double)vb - vk);
 }
 
-__global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) {
+template <int kThreads, int kMaxFlank, int kInFlight>
+__global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, uint32_t first_rec) {
+    constexpr int kWaves = kThreads / 64;
+    constexpr int kBinsPerThread = kBins / kThreads > 0 ? kBins / kThreads : 1;
     __shared__ uint32_t s_cnt[kBins];
-    __shared__ unsigned long long s_sum[kBins];            // multi-level sums; first doubles as the flank-window buffers
+    __shared__ uint32_t s_win[2][kMaxFlank];               // depths of the two flank windows
+    __shared__ uint32_t s_med[4];                          // per window: the two order statistics its median reads
     __shared__ uint32_t s_wc[kWaves];
     __shared__ unsigned long long s_ws[kWaves];
     __shared__ uint32_t s_max, s_overflow, s_sel_bin, s_sel_cnt;
-    __shared__ unsigned long long s_total, s_nz, s_sel_sum;
+    __shared__ unsigned long long s_total, s_nz, s_acc;
     __shared__ uint32_t s_qval[kQueries];
     __shared__ unsigned long long s_qsum[kQueries];
     __shared__ unsigned long long s_qrank[kQueries];
     __shared__ uint32_t s_qneed[kQueries];
     __shared__ uint32_t s_prem[3];
-    __shared__ double s_flank[2];
 
-    const uint32_t i = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const IntronRec R = T.recs[first_rec + blockIdx.x];        // wave-uniform: scalar loads
     Ctx C;
     C.d0 = T.diff;
     C.d1 = T.diff + T.plane_stride;
     C.c0 = T.carry;
     C.c1 = T.carry + T.plane_stride / kSeg;
-    const bool valid = T.valid[i] != 0 && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
+    const bool valid = R.valid != 0 && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
     C.plane = 2;
-    if (T.directionality != 0) C.plane = ((T.strand_plus[i] != 0) == (T.directionality > 0)) ? 1 : 0;
+    if (T.directionality != 0) C.plane = ((R.plus != 0) == (T.directionality > 0)) ? 1 : 0;
+    const int plane = C.plane;
 
-    const uint32_t b0 = T.blk_off[i], b1 = T.blk_off[i + 1];
-    const unsigned long long N = T.measured[i];
-    const uint64_t gS = T.g_start[i], gE = T.g_end[i];
+    // The counters of the row's tail, fetched now (uniform addresses: they land in scalar registers while the depth
+    // pass runs).  They were finalised by the kernels before this one.
+    uint32_t spl = 0, spr = 0, jl = 0, jr = 0, je = 0;
+    if (R.valid != 0 && !(T.ablate & 2u)) {
+        auto both = [&](const uint32_t* cnt, uint64_t n, int32_t idx) -> uint32_t {
+            if (idx < 0) return 0u;
+            return plane == 2 ? cnt[idx] + cnt[n + (uint64_t)idx] : cnt[(uint64_t)plane * n + (uint64_t)idx];
+        };
+        spl = both(T.sp_cnt, T.n_sp, R.sp_s);
+        spr = both(T.sp_cnt, T.n_sp, R.sp_e);
+        jl = both(T.left_cnt, T.n_ustart, R.us);
+        jr = both(T.right_cnt, T.n_uend, R.ue);
+        je = both(T.known_cnt, T.n_kj, R.kj);      // (Start,End) is a ref-sj junction: its reads were counted in place
+    }
 
-    // window buffers live in the (not yet used) sum array: win[0], win[1], sorted[0], sorted[1]
-    uint32_t* s_win0 = reinterpret_cast<uint32_t*>(s_sum);
-    uint32_t* s_win1 = s_win0 + kMaxFlank;
-    uint32_t* s_sorted0 = s_win1 + kMaxFlank;
-    uint32_t* s_sorted1 = s_sorted0 + kMaxFlank;
+    const uint32_t b0 = R.blk_off, nb = R.n_blk;
+    const unsigned long long N = R.measured;
+    const uint64_t gS = R.g_start, gE = R.g_end;
 
     // first / last flank_len nt of the intron, flank_offset nt inside it (full coordinates)
     uint64_t w0[2], w1[2];
     {
         const uint64_t ilen = gE - gS;
-        const uint64_t fo = T.flank_offset, fl = T.flank_len;
+        const uint64_t fo = T.flank_offset, fl = T.flank_len < (uint32_t)kMaxFlank ? T.flank_len : (uint32_t)kMaxFlank;
         w0[0] = gS + (fo < ilen ? fo : ilen);
         w1[0] = gS + (fo + fl < ilen ? fo + fl : ilen);
         w1[1] = gE - (fo < ilen ? fo : ilen);
@@ -206,7 +241,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
     }
 
     for (int k = tid; k < kBins; k += kThreads) s_cnt[k] = 0;
-    if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; }
+    if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; s_acc = 0; }
+    if (tid < 4) s_med[tid] = 0;
     __syncthreads();
 
     // ---------------- pass A: histogram (clipped) + window capture ----------------
@@ -220,59 +256,93 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                 if (w0[wi] >= w1[wi]) continue;
                 const uint64_t len = w1[wi] - w0[wi];
                 const uint64_t cs = plane_coord(T.pmap, w0[wi]);
-                uint32_t* dst = wi ? s_win1 : s_win0;
-                for_each_depth(C, cs, cs + len, [&](uint64_t x, uint32_t v, bool ok) { if (ok) dst[(uint32_t)(x - cs)] = v; });
+                uint32_t* dst = s_win[wi];
+                for_each_depth<kWaves>(C, cs, cs + len, [&](uint64_t x, uint32_t v, bool ok) { if (ok) dst[(uint32_t)(x - cs)] = v; });
                 nwin[wi] = (uint32_t)len;
             }
         }
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint64_t bs = T.blk_gstart[b], bc = T.blk_cstart[b];
-            const uint64_t bl = T.blk_len[b], be_c = bc + bl;
-            // the parts of the two windows inside this block, in plane coordinates (wave-uniform)
-            uint64_t ws[2] = {0, 0}, we[2] = {0, 0};
-            const uint32_t at0 = nwin[0], at1 = nwin[1];
+        for (uint32_t cb = 0; cb < nb; cb += kMaxBlk) {
+            // lane b keeps measured block cb + b: plane start, length, its slice of the flattened segment list, and
+            // the parts of the two flank windows that fall inside it (every wave builds the same registers)
+            const uint32_t nbc = nb - cb < kMaxBlk ? nb - cb : kMaxBlk;
+            const bool has = lane < nbc;
+            const BlkRec br = T.blks[b0 + cb + (has ? lane : 0u)];
+            const uint64_t d_bc = br.cstart;
+            const uint32_t d_bl = has ? br.len : 0u;
+            const uint32_t d_nseg = d_bl ? (uint32_t)((d_bc + d_bl - 1u) / kSeg - d_bc / kSeg + 1u) : 0u;
+            uint32_t d_wlo[2] = {0, 0}, d_wn[2] = {0, 0}, d_wat[2] = {0, 0};
             if (T.flank_use_measured) {
 #pragma unroll
                 for (int wi = 0; wi < 2; wi++) {
-                    const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = bs + bl < w1[wi] ? bs + bl : w1[wi];
-                    if (s < e) { ws[wi] = bc + (s - bs); we[wi] = bc + (e - bs); nwin[wi] += (uint32_t)(e - s); }
+                    const uint64_t bs = br.gstart;
+                    const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = bs + d_bl < w1[wi] ? bs + d_bl : w1[wi];
+                    if (d_bl && s < e) { d_wlo[wi] = (uint32_t)(s - bs); d_wn[wi] = (uint32_t)(e - s); }
+                    const uint32_t incl = wave_inclusive_scan_dpp(d_wn[wi]);
+                    d_wat[wi] = nwin[wi] + incl - d_wn[wi];
+                    nwin[wi] += lane_u32(incl, 63u);
                 }
             }
-            const uint64_t ws0 = ws[0], we0 = we[0], ws1 = ws[1], we1 = we[1];
-            for_each_segment(C, bc, be_c, [&](uint64_t seg0, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
-                const bool inner = seg0 >= bc && seg0 + kSeg <= be_c &&                         // whole segment measured
-                                   !(seg0 < we0 && seg0 + kSeg > ws0) && !(seg0 < we1 && seg0 + kSeg > ws1);
-                const bool flat = v0 == first && v1 == first && v2 == first && v3 == first;
-                if (inner && __ballot(flat) == ~0ull) {
-                    // depth is piecewise constant: most segments hold one value 256 times -> one LDS atomic
-                    if (lane == 0) { if (first < (uint32_t)kBins) atomicAdd(&s_cnt[first], (uint32_t)kSeg); else ovf = true; }
-                    return;
-                }
-                const uint32_t vv[4] = {v0, v1, v2, v3};
+            const uint32_t d_seg_end = wave_inclusive_scan_dpp(d_nseg);       // lanes >= nbc hold the total
+            const uint32_t d_seg_start = d_seg_end - d_nseg;
+            const uint32_t S = lane_u32(d_seg_end, 63u);
+
+            for (uint32_t s0 = wave; s0 < S; s0 += kWaves * kInFlight) {
+                Seg sg[kInFlight];
+                uint32_t sb[kInFlight];
+                uint64_t sk[kInFlight];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint64_t x = e0 + j;
-                    const uint32_t v = vv[j];
-                    const bool ok = x >= bc && x < be_c;
-                    // wave-aggregated histogram update: lanes that share the first valid lane's value add once
-                    const uint64_t act = __ballot(ok);
-                    if (!act) continue;
-                    const uint32_t lead = __shfl(v, __ffsll((long long)act) - 1);
-                    const uint64_t same = __ballot(ok && v == lead);
-                    if (ok) {
-                        if (v == lead) {
-                            if (lane == (uint32_t)(__ffsll((long long)same) - 1)) {
-                                if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], (uint32_t)__popcll(same)); else ovf = true;
-                            }
-                        } else {
-                            if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
-                        }
-                        if (x >= ws0 && x < we0) s_win0[at0 + (uint32_t)(x - ws0)] = v;
-                        if (x >= ws1 && x < we1) s_win1[at1 + (uint32_t)(x - ws1)] = v;
-                    }
+                for (int j = 0; j < kInFlight; j++) {
+                    const uint32_t s = s0 + j * kWaves;
+                    const uint32_t sc = s < S ? s : S - 1u;           // past the end: load the last segment again, unused
+                    sb[j] = (uint32_t)__popcll(__ballot(d_seg_end <= sc));        // blocks that end before segment sc
+                    sk[j] = lane_u64(d_bc, sb[j]) / kSeg + (sc - lane_u32(d_seg_start, sb[j]));
+                    sg[j] = load_seg(C, sk[j], lane);
                 }
-            });
+#pragma unroll
+                for (int j = 0; j < kInFlight; j++) {
+                    if (s0 + j * kWaves >= S) continue;                // wave-uniform
+                    const uint32_t b = sb[j];
+                    const uint64_t bc = lane_u64(d_bc, b), be_c = bc + lane_u32(d_bl, b);
+                    const uint32_t wn0 = lane_u32(d_wn[0], b), wn1 = lane_u32(d_wn[1], b);
+                    const uint64_t ws0 = wn0 ? bc + lane_u32(d_wlo[0], b) : 0ull, we0 = ws0 + wn0;
+                    const uint64_t ws1 = wn1 ? bc + lane_u32(d_wlo[1], b) : 0ull, we1 = ws1 + wn1;
+                    const uint32_t at0 = lane_u32(d_wat[0], b), at1 = lane_u32(d_wat[1], b);
+                    emit_seg(sg[j], sk[j], lane, [&](uint64_t seg0, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+                        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
+                        const bool inner = seg0 >= bc && seg0 + kSeg <= be_c &&                         // whole segment measured
+                                           !(seg0 < we0 && seg0 + kSeg > ws0) && !(seg0 < we1 && seg0 + kSeg > ws1);
+                        const bool flat = v0 == first && v1 == first && v2 == first && v3 == first;
+                        if (inner && __ballot(flat) == ~0ull) {
+                            // depth is piecewise constant: most segments hold one value 256 times -> one LDS atomic
+                            if (lane == 0) { if (first < (uint32_t)kBins) atomicAdd(&s_cnt[first], (uint32_t)kSeg); else ovf = true; }
+                            return;
+                        }
+                        const uint32_t vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint64_t x = e0 + q;
+                            const uint32_t v = vv[q];
+                            const bool ok = x >= bc && x < be_c;
+                            // wave-aggregated histogram update: lanes that share the first valid lane's value add once
+                            const uint64_t act = __ballot(ok);
+                            if (!act) continue;
+                            const uint32_t lead = __shfl(v, __ffsll((long long)act) - 1);
+                            const uint64_t same = __ballot(ok && v == lead);
+                            if (ok) {
+                                if (v == lead) {
+                                    if (lane == (uint32_t)(__ffsll((long long)same) - 1)) {
+                                        if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], (uint32_t)__popcll(same)); else ovf = true;
+                                    }
+                                } else {
+                                    if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
+                                }
+                                if (x >= ws0 && x < we0) s_win[0][at0 + (uint32_t)(x - ws0)] = v;
+                                if (x >= ws1 && x < we1) s_win[1][at1 + (uint32_t)(x - ws1)] = v;
+                            }
+                        }
+                    });
+                }
+            }
         }
         if (ovf) s_overflow = 1;
     } else {
@@ -282,8 +352,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
             uint32_t n = 0;
             if (w0[wi] < w1[wi]) {
                 if (T.flank_use_measured) {
-                    for (uint32_t b = b0; b < b1; b++) {
-                        const uint64_t bs = T.blk_gstart[b], be = bs + T.blk_len[b];
+                    for (uint32_t b = b0; b < b0 + nb; b++) {
+                        const uint64_t bs = T.blks[b].gstart, be = bs + T.blks[b].len;
                         const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
                         if (s < e) n += (uint32_t)(e - s);
                     }
@@ -291,8 +361,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                     n = (uint32_t)(w1[wi] - w0[wi]);
                 }
             }
-            uint32_t* dst = wi ? s_win1 : s_win0;
-            for (uint32_t k = tid; k < n; k += kThreads) dst[k] = 0;
+            for (uint32_t k = tid; k < n; k += kThreads) s_win[wi][k] = 0;
             nwin[wi] = n;
         }
     }
@@ -302,9 +371,9 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         // depth beyond the single-level histogram somewhere: maximum, total and non-zero count by a pass of their own
         uint32_t vmax = 0;
         unsigned long long tsum = 0, nz = 0;
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint64_t bc = T.blk_cstart[b];
-            for_each_depth(C, bc, bc + T.blk_len[b], [&](uint64_t, uint32_t v, bool ok) {
+        for (uint32_t b = b0; b < b0 + nb; b++) {
+            const uint64_t bc = T.blks[b].cstart;
+            for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
                 if (ok) { vmax = v > vmax ? v : vmax; tsum += v; nz += v ? 1u : 0u; }
             });
         }
@@ -320,21 +389,30 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         s_nz = N - s_cnt[0];
     }
 
-    // ---------------- flank medians: rank-by-counting sort of both windows ----------------
+    // ---------------- flank medians: rank of every window element by counting ----------------
+    PctRanks fq[2];
+    fq[0] = percentile_ranks(nwin[0], 50u, T.pct_interpolate != 0);
+    fq[1] = percentile_ranks(nwin[1], 50u, T.pct_interpolate != 0);
     {
         const uint32_t n0 = nwin[0], n1 = nwin[1];
         for (uint32_t e = tid; e < n0 + n1; e += kThreads) {
-            const bool second = e >= n0;
-            const uint32_t* w = second ? s_win1 : s_win0;
-            uint32_t* so = second ? s_sorted1 : s_sorted0;
-            const uint32_t n = second ? n1 : n0, idx = second ? e - n0 : e;
+            const int wi = e >= n0 ? 1 : 0;
+            const uint32_t* w = s_win[wi];
+            const uint32_t n = wi ? n1 : n0, idx = wi ? e - n0 : e;
             const uint32_t v = w[idx];
             uint32_t r = 0;
             for (uint32_t j = 0; j < n; j++) {
                 const uint32_t o = w[j];
                 r += (o < v || (o == v && j < idx)) ? 1u : 0u;
             }
-            so[r] = v;
+            // the ranks are a permutation: one writer per slot
+            if (wi == 0) {
+                if (r == fq[0].ra) s_med[0] = v;
+                if (fq[0].need_b && r == fq[0].rb) s_med[1] = v;
+            } else {
+                if (r == fq[1].ra) s_med[2] = v;
+                if (fq[1].need_b && r == fq[1].rb) s_med[3] = v;
+            }
         }
     }
 
@@ -347,26 +425,14 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         s_qrank[1] = hi; s_qneed[1] = (N > 0 && hi > 0 && hi < N) ? 1u : 0u;
         const uint32_t pcts[3] = {25u, 50u, 75u};
         for (int p = 0; p < 3; p++) {
-            const unsigned long long num = (N + 1ull) * pcts[p];
-            const unsigned long long k = num / 100ull;
-            const uint32_t rem = (uint32_t)(num % 100ull);
-            unsigned long long ra = 0, rb = 0;
-            bool nb = false;
-            if (N > 0) {
-                if (k < 1) ra = 0;
-                else if (k >= N) ra = N - 1;
-                else { ra = k - 1; rb = k; nb = T.pct_interpolate != 0 && rem != 0; }
-            }
-            s_qrank[2 + 2 * p] = ra; s_qneed[2 + 2 * p] = N > 0 ? 1u : 0u;
-            s_qrank[3 + 2 * p] = rb; s_qneed[3 + 2 * p] = nb ? 1u : 0u;
-            s_prem[p] = rem;
+            const PctRanks q = percentile_ranks(N, pcts[p], T.pct_interpolate != 0);
+            s_qrank[2 + 2 * p] = q.ra; s_qneed[2 + 2 * p] = q.need_a ? 1u : 0u;
+            s_qrank[3 + 2 * p] = q.rb; s_qneed[3 + 2 * p] = q.need_b ? 1u : 0u;
+            s_prem[p] = q.rem;
         }
     }
     if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
     __syncthreads();
-    if (tid < 2) {      // window medians (the sorted windows are complete after the barrier above)
-        s_flank[tid] = percentile_sorted(tid ? s_sorted1 : s_sorted0, nwin[tid], 50u, T.pct_interpolate != 0);
-    }
 
     if (N > 0 && !overflow) {
         // single level: bins are the depths themselves
@@ -381,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
         uint32_t pre;
         unsigned long long pre_sum;
-        block_excl_scan(tot, tsum, pre, pre_sum, s_wc, s_ws);
+        block_excl_scan<kWaves>(tot, tsum, pre, pre_sum, s_wc, s_ws);
         if (tid == kThreads - 1) s_total = pre_sum + tsum;       // sum of all depths
 #pragma unroll
         for (int q = 0; q < kQueries; q++) {
@@ -400,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         }
         __syncthreads();
     } else if (N > 0) {
-        // multi-level radix select, one descent per query (the window buffers are dead by now: s_flank holds the medians)
+        // multi-level radix select, one descent per query; a sum query (q < 2) then adds the values below the selected one
         __syncthreads();
         int bits = 32 - __clz((int)s_max);
         int levels = (bits + kBinBits - 1) / kBinBits;
@@ -408,54 +474,61 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         for (int q = 0; q < kQueries; q++) {
             if (!s_qneed[q]) continue;                     // uniform across the block
             unsigned long long r = s_qrank[q];
-            unsigned long long sum_below = 0;
             uint32_t prefix = 0;
             for (int lv = 0; lv < levels; lv++) {
                 const int shift = kBinBits * (levels - 1 - lv);
-                for (int k = tid; k < kBins; k += kThreads) { s_cnt[k] = 0; s_sum[k] = 0; }
+                for (int k = tid; k < kBins; k += kThreads) s_cnt[k] = 0;
                 __syncthreads();
-                for (uint32_t b = b0; b < b1; b++) {
-                    const uint64_t bc = T.blk_cstart[b];
-                    for_each_depth(C, bc, bc + T.blk_len[b], [&](uint64_t, uint32_t v, bool ok) {
+                for (uint32_t b = b0; b < b0 + nb; b++) {
+                    const uint64_t bc = T.blks[b].cstart;
+                    for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
                         const bool in = ok && (lv == 0 || (v >> (shift + kBinBits)) == prefix);
-                        if (in) {
-                            const uint32_t bin = (v >> shift) & (uint32_t)(kBins - 1);
-                            atomicAdd(&s_cnt[bin], 1u);
-                            atomicAdd(&s_sum[bin], (unsigned long long)v);
-                        }
+                        if (in) atomicAdd(&s_cnt[(v >> shift) & (uint32_t)(kBins - 1)], 1u);
                     });
                 }
                 __syncthreads();
                 uint32_t c[kBinsPerThread];
-                unsigned long long sm[kBinsPerThread];
                 uint32_t tot = 0;
-                unsigned long long tsum = 0;
 #pragma unroll
                 for (int j = 0; j < kBinsPerThread; j++) {
                     c[j] = s_cnt[tid * kBinsPerThread + j];
-                    sm[j] = s_sum[tid * kBinsPerThread + j];
                     tot += c[j];
-                    tsum += sm[j];
                 }
                 uint32_t pre;
                 unsigned long long pre_sum;
-                block_excl_scan(tot, tsum, pre, pre_sum, s_wc, s_ws);
+                block_excl_scan<kWaves>(tot, 0ull, pre, pre_sum, s_wc, s_ws);
                 if (r >= pre && r < (unsigned long long)pre + tot) {
-                    unsigned long long run = pre, s = pre_sum;
+                    unsigned long long run = pre;
 #pragma unroll
                     for (int j = 0; j < kBinsPerThread; j++) {
-                        if (r < run + c[j]) { s_sel_bin = tid * kBinsPerThread + j; s_sel_cnt = (uint32_t)run; s_sel_sum = s; break; }
+                        if (r < run + c[j]) { s_sel_bin = tid * kBinsPerThread + j; s_sel_cnt = (uint32_t)run; break; }
                         run += c[j];
-                        s += sm[j];
                     }
                 }
                 __syncthreads();
                 prefix = (prefix << kBinBits) | s_sel_bin;
                 r -= s_sel_cnt;
-                sum_below += s_sel_sum;
                 __syncthreads();
             }
-            if (tid == 0) { s_qval[q] = prefix; s_qsum[q] = sum_below + (unsigned long long)prefix * r; }
+            // prefix = the value at the rank; r = the rank's position among the copies of that value
+            unsigned long long below = 0;
+            if (q < 2) {
+                unsigned long long part = 0;
+                for (uint32_t b = b0; b < b0 + nb; b++) {
+                    const uint64_t bc = T.blks[b].cstart;
+                    for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
+                        if (ok && v < prefix) part += v;
+                    });
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+                if (lane == 0 && part) atomicAdd(&s_acc, part);
+                __syncthreads();
+                below = s_acc;
+                __syncthreads();
+                if (tid == 0) s_acc = 0;
+            }
+            if (tid == 0) { s_qval[q] = prefix; s_qsum[q] = below + (unsigned long long)prefix * r; }
         }
         __syncthreads();
     } else {
@@ -464,7 +537,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
 
     // ---------------- the row ----------------
     if (tid == 0) {
-        const double flank0 = s_flank[0], flank1 = s_flank[1];
+        const double flank0 = percentile_value(fq[0], s_med[0], s_med[1]);
+        const double flank1 = percentile_value(fq[1], s_med[2], s_med[3]);
         const unsigned long long total = s_total, nzc = s_nz;
         double coverage = 0.0, depth = 0.0, pv[3] = {0.0, 0.0, 0.0};
         if (N > 0) {
@@ -479,20 +553,10 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
                 else pv[p] = vk;
             }
         }
-        const int plane = C.plane;
-        uint32_t spl = 0, spr = 0, jl = 0, jr = 0, je = 0;
-        if (valid && !(T.ablate & 2u)) {
-            const int32_t a = T.sp_idx_start[i], b = T.sp_idx_end[i];
-            if (a >= 0) spl = plane == 2 ? T.sp_cnt[a] + T.sp_cnt[(uint64_t)T.n_sp + a] : T.sp_cnt[(uint64_t)plane * T.n_sp + a];
-            if (b >= 0) spr = plane == 2 ? T.sp_cnt[b] + T.sp_cnt[(uint64_t)T.n_sp + b] : T.sp_cnt[(uint64_t)plane * T.n_sp + b];
-            const int32_t us = T.us_idx[i], ue = T.ue_idx[i];
-            if (us >= 0) jl = plane == 2 ? T.left_cnt[us] + T.left_cnt[(uint64_t)T.n_ustart + us] : T.left_cnt[(uint64_t)plane * T.n_ustart + us];
-            if (ue >= 0) jr = plane == 2 ? T.right_cnt[ue] + T.right_cnt[(uint64_t)T.n_uend + ue] : T.right_cnt[(uint64_t)plane * T.n_uend + ue];
-            const int32_t kj = T.kj_idx[i];
+        if (R.valid != 0 && !(T.ablate & 2u) && R.kj < 0) {
+            // (Start,End) is not in ref-sj: look it up among the novel junctions
             const uint64_t span = gE - gS;
-            if (kj >= 0) {          // (Start,End) is a ref-sj junction: its reads were counted in place
-                je = plane == 2 ? T.known_cnt[kj] + T.known_cnt[(uint64_t)T.n_kj + kj] : T.known_cnt[(uint64_t)plane * T.n_kj + kj];
-            } else if (span < (1ull << kJuncSpanBits) && gS < kJuncMaxGlobal && T.n_unique > 0) {
+            if (span < (1ull << kJuncSpanBits) && gS < kJuncMaxGlobal && T.n_unique > 0) {
                 const uint64_t key0 = (gS << kJuncLeftShift) | (span << 1);
                 uint64_t lo_i = 0, hi_i = T.n_unique;
                 while (lo_i < hi_i) {
@@ -518,6 +582,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
         else if (maxflank > depth * T.warn_nonuniform_rel + T.warn_nonuniform_abs) warn = 4;
         else warn = 0;
         const uint64_t n = T.n_intron;
+        const uint64_t i = R.row;
         T.out_f64[0 * n + i] = coverage;
         T.out_f64[1 * n + i] = depth;
         T.out_f64[2 * n + i] = pv[0];
@@ -537,9 +602,13 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T) 
 
 }   // namespace
 
-void launch_intron_stats(const IntronTables& T, hipStream_t s) {
-    if (T.n_intron == 0) return;
-    hipLaunchKernelGGL(intron_stats_kernel, dim3(T.n_intron), dim3(kThreads), 0, s, T);
+// T.recs is sorted by size class (kernels.h: StatsClasses), longest intron first inside a class; every class is one
+// launch with its own workgroup size.  The small workgroups keep their flank windows in a 64-entry LDS buffer: the
+// host puts every intron into the 256-thread class when flank_len is larger.
+void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s) {
+    if (K.count[0]) hipLaunchKernelGGL((intron_stats_kernel<1024, kStatsMaxFlank, 4>), dim3(K.count[0]), dim3(1024), 0, s, T, K.first[0]);
+    if (K.count[1]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, 4>), dim3(K.count[1]), dim3(256), 0, s, T, K.first[1]);
+    if (K.count[2]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, 4>), dim3(K.count[2]), dim3(64), 0, s, T, K.first[2]);
 }
 
 }   // namespace dev
