@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "../../include/irf.h"
@@ -114,6 +115,7 @@ struct irf_ctx {
     DevBuf<dev::IntronRec> d_in_recs;              // one record per intron, in launch order (size classes)
     DevBuf<dev::BlkRec> d_blk_recs;
     dev::StatsClasses stats_classes;
+    DevBuf<uint32_t> d_stats_wg_off[2];
     DevBuf<uint64_t> d_us_pos, d_ue_pos, d_known_keys;
     DevBuf<uint8_t> d_known_dir;
     DevBuf<uint32_t> d_known_kjidx, d_known_cnt;   // known-junction rows and their [2][n_kj] counters
@@ -497,39 +499,62 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             uei[i] = (int32_t)(std::lower_bound(ue.begin(), ue.end(), ge[i]) - ue.begin());
         }
         n_us = (uint32_t)us.size(); n_ue = (uint32_t)ue.size();
-        // one record per intron, sorted into the size classes of the statistics kernel (kernels.h: StatsClasses),
-        // longest first inside a class so that the long ones do not trail the launch
+        // one record per intron, laid out by size class and workgroup (kernels.h: StatsClasses): inside a class the
+        // introns go, longest first, to the workgroup with the least work so far (cost = segments + a fixed part)
         {
             const uint64_t small_max = P.flank_len <= dev::kStatsSmallFlank ? env_u64("IRF_STATS_SMALL_MAX", dev::kStatsSmallMax) : 0ull;
-            const uint64_t huge_min = env_u64("IRF_STATS_HUGE_MIN", dev::kStatsHugeMin);
-            auto cls = [&](uint32_t i) -> int {
-                const uint64_t m = ref.in_measured[i];
-                return m >= huge_min ? 0 : (m <= small_max ? 2 : 1);
-            };
-            std::vector<uint32_t> order(n_intron);
-            for (uint32_t i = 0; i < n_intron; i++) order[i] = i;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-                const int ca = cls(a), cb = cls(b);
-                if (ca != cb) return ca < cb;
-                return ref.in_measured[a] > ref.in_measured[b];
-            });
-            std::vector<dev::IntronRec> recs(n_intron);
-            memset(&stats_classes, 0, sizeof stats_classes);
-            for (uint32_t k = 0; k < n_intron; k++) {
-                const uint32_t i = order[k];
-                dev::IntronRec& r = recs[k];
-                memset(&r, 0, sizeof r);
-                r.g_start = gs[i]; r.g_end = ge[i]; r.measured = ref.in_measured[i];
-                r.blk_off = ref.in_blk_off[i]; r.n_blk = ref.in_blk_off[i + 1] - ref.in_blk_off[i];
-                r.sp_s = sis[i]; r.sp_e = sie[i]; r.us = usi[i]; r.ue = uei[i]; r.kj = kji[i];
-                r.row = i; r.valid = valid[i]; r.plus = plus[i];
-                const int c = cls(i);
-                if (stats_classes.count[c]++ == 0) stats_classes.first[c] = k;
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
+            if (n_cu < 1) n_cu = 1;
+            const uint32_t wgs_per_cu[2] = {(uint32_t)env_u64("IRF_STATS_WGS_BIG", 6), (uint32_t)env_u64("IRF_STATS_WGS_SMALL", 24)};
+            std::vector<uint32_t> members[2];
+            for (uint32_t i = 0; i < n_intron; i++)
+                if (ref.in_measured[i] >= (1ull << 28)) return fail(IRF_E_RANGE, "an intron of ref-cover.bed has 2^28 or more measured bases");
+            for (uint32_t i = 0; i < n_intron; i++) members[ref.in_measured[i] <= small_max ? 1 : 0].push_back(i);
+            std::vector<dev::IntronRec> recs;
+            recs.reserve(n_intron + 1);
+            std::vector<uint32_t> wg_off[2];
+            for (int c = 0; c < 2; c++) {
+                auto& m = members[c];
+                std::stable_sort(m.begin(), m.end(), [&](uint32_t a, uint32_t b) { return ref.in_measured[a] > ref.in_measured[b]; });
+                uint32_t n_wg = std::min<uint64_t>((uint64_t)n_cu * std::max(wgs_per_cu[c], 1u), m.size());
+                stats_classes.n_wg[c] = n_wg;
+                std::vector<std::vector<uint32_t>> lists(n_wg);
+                typedef std::pair<uint64_t, uint32_t> Load;          // (cost so far, workgroup)
+                std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+                for (uint32_t w = 0; w < n_wg; w++) heap.push(Load(0, w));
+                for (uint32_t i : m) {
+                    Load l = heap.top(); heap.pop();
+                    lists[l.second].push_back(i);
+                    const uint64_t nb = ref.in_blk_off[i + 1] - ref.in_blk_off[i];
+                    l.first += ref.in_measured[i] / dev::kDepthSegment + 2 * nb + 8;
+                    heap.push(l);
+                }
+                wg_off[c].assign(1, (uint32_t)recs.size());
+                for (uint32_t w = 0; w < n_wg; w++) {
+                    for (uint32_t i : lists[w]) {
+                        dev::IntronRec r;
+                        memset(&r, 0, sizeof r);
+                        r.g_start = gs[i]; r.g_end = ge[i]; r.measured = ref.in_measured[i];
+                        r.blk_off = ref.in_blk_off[i]; r.n_blk = ref.in_blk_off[i + 1] - ref.in_blk_off[i];
+                        r.sp_s = sis[i]; r.sp_e = sie[i]; r.us = usi[i]; r.ue = uei[i]; r.kj = kji[i];
+                        r.row = i;
+                        uint32_t need = 0, prem = 0;
+                        dev::stats_queries(r.measured, P.trim_centre_pct, P.pct_interpolate != 0, r.qrank, &need, &prem);
+                        r.flags = (valid[i] ? 1u : 0u) | (plus[i] ? 2u : 0u) | (need << 8);
+                        r.prem = prem;
+                        recs.push_back(r);
+                    }
+                    wg_off[c].push_back((uint32_t)recs.size());
+                }
             }
-            std::vector<dev::BlkRec> blks(ref.blk_start.size());
-            for (size_t b = 0; b < blks.size(); b++) { blks[b].gstart = bgs[b]; blks[b].cstart = bcs[b]; blks[b].len = bl[b]; blks[b].pad = 0; }
-            if (blks.empty()) blks.resize(1);          // the kernel's clamped descriptor load needs one entry
+            if (recs.empty()) recs.resize(1);
+            std::vector<dev::BlkRec> blks(ref.blk_start.size() + 1);      // + one spare entry: the kernel's clamped descriptor load
+            for (size_t b = 0; b + 1 < blks.size(); b++) { blks[b].gstart = bgs[b]; blks[b].cstart = bcs[b]; blks[b].len = bl[b]; blks[b].pad = 0; }
+            memset(&blks.back(), 0, sizeof(dev::BlkRec));
             TRY(upload(this, d_in_recs, recs)); TRY(upload(this, d_blk_recs, blks));
+            TRY(upload(this, d_stats_wg_off[0], wg_off[0])); TRY(upload(this, d_stats_wg_off[1], wg_off[1]));
+            stats_classes.wg_off[0] = d_stats_wg_off[0].p; stats_classes.wg_off[1] = d_stats_wg_off[1].p;
         }
         TRY(upload(this, d_us_pos, us)); TRY(upload(this, d_ue_pos, ue));
         TRY(alloc_zero(this, d_left_cnt, (size_t)n_us * 2));

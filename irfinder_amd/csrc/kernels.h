@@ -147,33 +147,64 @@ void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s);
 void launch_known_lookups(const JuncLookupTables& J, hipStream_t s);
 
 // ---- per-intron statistics + IR table --------------------------------------------
-// Everything a row needs besides depth, one 64-byte record per intron (the kernel reads it with scalar loads).
+// Everything a row needs besides depth, one 128-byte record per intron.  The kernel keeps a record one dword per lane
+// (stats.hip: header pipeline), so the field order below is its ABI: dword index in the comment.
 struct IntronRec {
-    uint64_t g_start, g_end;       // full coordinates of the intron
-    uint64_t measured;             // sum of the measured block lengths
-    uint32_t blk_off, n_blk;       // measured blocks: blks[blk_off .. blk_off + n_blk)
-    int32_t sp_s, sp_e;            // index into sp_cnt of the point at Start / End (-1: none)
-    int32_t us, ue;                // index into left_cnt / right_cnt
-    int32_t kj;                    // row of the known-junction table for (Start,End), -1 if not in ref-sj
-    uint32_t row;                  // row of the IR table (= record index in ref-cover.bed)
-    uint8_t valid;                 // chromosome present in the BAM header and owned
-    uint8_t plus;                  // 1 unless strand == '-'
-    uint8_t pad[2];
+    uint64_t g_start, g_end;       // 0-3   full coordinates of the intron
+    uint64_t measured;             // 4-5   sum of the measured block lengths (N)
+    uint32_t blk_off, n_blk;       // 6,7   measured blocks: blks[blk_off .. blk_off + n_blk)
+    int32_t sp_s, sp_e;            // 8,9   index into sp_cnt of the point at Start / End (-1: none)
+    int32_t us, ue;                // 10,11 index into left_cnt / right_cnt
+    int32_t kj;                    // 12    row of the known-junction table for (Start,End), -1 if not in ref-sj
+    uint32_t row;                  // 13    row of the IR table (= record index in ref-cover.bed)
+    uint32_t flags;                // 14    bit0 valid (chromosome in the BAM header and owned), bit1 '+' strand, bits 8..15 qneed
+    uint32_t prem;                 // 15    interpolation remainders of p25 | p50 << 8 | p75 << 16
+    uint32_t qrank[8];             // 16-23 the rank queries (stats_queries below)
+    uint32_t pad[8];
 };
-static_assert(sizeof(IntronRec) == 64, "IntronRec is one 64-byte line");
+static_assert(sizeof(IntronRec) == 128, "IntronRec is 32 dwords");
 struct BlkRec {                    // one measured block
     uint64_t gstart;               // full coordinates
     uint64_t cstart;               // plane (compact) coordinates
     uint32_t len;
     uint32_t pad;
 };
-// recs is sorted into size classes (by measured bases), longest first inside a class: class c = records
-// [first[c], first[c] + count[c]); 0 = huge (1024-thread workgroups), 1 = 256 threads, 2 = small (64 threads)
-struct StatsClasses { uint32_t first[3], count[3]; };
+
+// The rank queries every statistic of an intron with N measured bases reduces to (0-based ranks into the sorted
+// depths).  q0, q1: "sum of the r smallest" at r = skip and r = N - skip for the trimmed mean (OQ-8:
+// skip = floor(N (100 - centre) / 200)); q2..q7: the order statistics k-1 and k of p25, p50, p75 (OQ-7:
+// (N + 1) p / 100 = k + rem / 100).  need bit q: the query has to be answered.
+inline void stats_queries(uint64_t N, uint32_t trim_centre_pct, bool interpolate, uint32_t qrank[8], uint32_t* need, uint32_t* prem) {
+    const uint64_t skip = N * (uint64_t)(100u - trim_centre_pct) / 200ull;
+    const uint64_t lo = skip, hi = N - skip;
+    *need = 0; *prem = 0;
+    qrank[0] = (uint32_t)lo; if (N > 0 && lo > 0 && lo < N) *need |= 1u;
+    qrank[1] = (uint32_t)hi; if (N > 0 && hi > 0 && hi < N) *need |= 2u;
+    const uint32_t pcts[3] = {25u, 50u, 75u};
+    for (int p = 0; p < 3; p++) {
+        const uint64_t num = (N + 1ull) * pcts[p];
+        const uint64_t k = num / 100ull;
+        const uint32_t rem = (uint32_t)(num % 100ull);
+        uint64_t ra = 0, rb = 0;
+        bool nb = false;
+        if (N > 0) {
+            if (k < 1) ra = 0;
+            else if (k >= N) ra = N - 1;
+            else { ra = k - 1; rb = k; nb = interpolate && rem != 0; }
+        }
+        qrank[2 + 2 * p] = (uint32_t)ra; if (N > 0) *need |= 1u << (2 + 2 * p);
+        qrank[3 + 2 * p] = (uint32_t)rb; if (nb) *need |= 1u << (3 + 2 * p);
+        *prem |= rem << (8 * p);
+    }
+}
+
+// recs is laid out by size class (by measured bases) and, inside a class, by workgroup: the host deals the introns of a
+// class, longest first, to the least loaded workgroup.  Class 0: 256-thread workgroups, class 1: small introns,
+// 64-thread workgroups.  wg_off[c] is a device array of n_wg[c] + 1 record indices.
+struct StatsClasses { const uint32_t* wg_off[2]; uint32_t n_wg[2]; };
 constexpr uint32_t kStatsMaxFlank = 512;       // flank_len limit (LDS window buffers)
 constexpr uint32_t kStatsSmallFlank = 64;      // ... of the 64-thread class
-constexpr uint64_t kStatsSmallMax = 2048;      // class 2: measured <= this
-constexpr uint64_t kStatsHugeMin = 65536;      // class 0: measured >= this
+constexpr uint64_t kStatsSmallMax = 8192;      // class 1: measured <= this
 
 struct IntronTables {
     uint32_t n_intron;

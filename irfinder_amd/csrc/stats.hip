@@ -23,29 +23,53 @@
 // HBM-bound: 4 B (one strand) or 8 B (both) per measured base, read once; the
 // first/last-50-nt windows are captured from the same pass.
 //
-// Shape.  200 k introns of very different sizes (median 1.7 k measured bases, tail to 0.5 M): a short intron is
-// a chain of dependent round trips (record -> block descriptors -> planes), a long one is a stream.  So
-//   * the host sorts the introns into three size classes, longest first inside a class, and each class gets its own
-//     workgroup size (1024 / 256 / 64 threads): a CU holds 32 short introns at once instead of 8;
-//   * everything the row needs besides depth sits in ONE 64-byte record per intron (scalar loads), and the counters
-//     of the row's tail are fetched at the top, under the depth pass;
+// Shape.  200 k introns of very different sizes (median 1.7 k measured bases, tail to 0.5 M).  Measured on MI355X the
+// kernel is bound by instruction issue and by chains of dependent round trips, not by HBM bandwidth, so:
+//   * two size classes, each a persistent launch with its own workgroup size (256 / 64 threads); the host deals the
+//     introns of a class, longest first, to the least loaded workgroup (no long intron trails the launch);
+//   * everything the row needs besides depth sits in ONE 128-byte record per intron, rank queries included; the
+//     record two introns ahead, the block descriptors and the row's counters one intron ahead are fetched while the
+//     workgroup still works on the current intron (header pipeline);
 //   * the measured blocks of an intron are flattened into one list of segments: lane b of every wave keeps the
-//     descriptor of block b in registers (no LDS, no barrier), a ballot finds the block of a segment, and a wave has
-//     kInFlight segments of loads outstanding before it touches the first;
-//   * depth is piecewise constant, so a segment that holds one value 256 times (most do) costs ONE LDS atomic, and
-//     mixed segments aggregate equal values per wave before touching the histogram.
+//     descriptor of block b in registers (no LDS, no barrier), a ballot finds the block of a segment; the loads of
+//     kInFlight segments are issued back to back before any result is touched;
+//   * per segment, everything wave-uniform is computed relative to the segment start on the scalar unit; a lane
+//     whose four positions are measured and equal is one histogram entry of weight 4, and equal lanes are merged by
+//     the wave (depth is piecewise constant: a segment that holds one value 256 times costs ONE LDS atomic);
+//   * flank medians by radix select over ballots, rank queries by a DPP scan over the owning thread's bins.
 #include "kernels.h"
+
+#include <cstdio>
+#include <vector>
 
 namespace irf {
 namespace dev {
 
 namespace {
 
+#ifndef STATS_INFLIGHT_BIG
+#define STATS_INFLIGHT_BIG 2
+#endif
+#ifndef STATS_INFLIGHT_SMALL
+#define STATS_INFLIGHT_SMALL 2
+#endif
+#ifndef STATS_MIN_WAVES
+#define STATS_MIN_WAVES 6
+#endif
 constexpr int kBinBits = 10;
 constexpr int kBins = 1 << kBinBits;
 constexpr int kQueries = 8;
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 constexpr uint32_t kMaxBlk = 64;    // measured blocks per descriptor chunk: one per lane
+
+#ifdef STATS_PROF
+// diagnostic build only (tools/build_variant.sh -DSTATS_PROF): wall-clock ticks (10 ns) per phase and workgroup
+constexpr uint32_t kProfMax = 1u << 16;
+__device__ uint32_t g_prof[kProfMax][8];
+#define PROF_MARK(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
+#else
+#define PROF_MARK(k) do { } while (0)
+#endif
 
 struct Ctx {
     const int32_t* d0;              // difference planes
@@ -69,11 +93,51 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
     return (uint32_t)v;
 }
 
+// Inclusive prefix sum inside every row of 16 lanes.
+__device__ __forceinline__ uint32_t row_inclusive_scan_dpp(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    return (uint32_t)v;
+}
+
+// OR over the 64 lanes (same DPP ladder as the scan; the result is what lane 63 ends up with)
+__device__ __forceinline__ uint32_t wave_or_dpp(uint32_t x) {
+    int v = (int)x;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+// k-th smallest (0-based) of the values held by the lanes of cand (wave-uniform mask, k < popcount), v < 2^nbits:
+// binary radix select, one ballot per bit; everything but the bit test runs on the scalar unit.
+__device__ __forceinline__ uint32_t wave_kth(uint32_t v, uint64_t cand, uint32_t k, int nbits) {
+    uint32_t res = 0;
+    for (int b = nbits - 1; b >= 0; b--) {
+        const uint64_t ones = __ballot(((v >> b) & 1u) != 0u) & cand;
+        const uint64_t zeros = cand & ~ones;
+        const uint32_t nz = (uint32_t)__popcll(zeros);
+        if (k < nz) { cand = zeros; } else { cand = ones; k -= nz; res |= 1u << b; }
+    }
+    return res;
+}
+
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, uint32_t src) {          // src is wave-uniform
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
 }
 __device__ __forceinline__ uint64_t lane_u64(uint64_t v, uint32_t src) {
     return (uint64_t)lane_u32((uint32_t)v, src) | ((uint64_t)lane_u32((uint32_t)(v >> 32), src) << 32);
+}
+
+// 64-bit field of a record kept one dword per lane: dwords at, at + 1
+__device__ __forceinline__ uint64_t lane_u64v(uint32_t rec, uint32_t at) {
+    return (uint64_t)lane_u32(rec, at) | ((uint64_t)lane_u32(rec, at + 1u) << 32);
 }
 
 __device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane) {
@@ -91,6 +155,31 @@ __device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane)
         s.a = *reinterpret_cast<const int4*>(C.d0 + e0);
         s.carry = C.c0[k];
     }
+    return s;
+}
+
+// The loads of one segment, issued without touching their results, so that a wave can have several segments
+// outstanding (load_seg adds the two strands at once, and with it waits for both loads).
+struct RawSeg { int4 u, v; uint32_t cu, cv; };
+__device__ __forceinline__ RawSeg issue_seg(const Ctx& C, uint64_t k, uint32_t lane) {
+    RawSeg r;
+    const uint64_t e0 = k * kSeg + lane * 4u;
+    const int32_t* pu = C.plane == 1 ? C.d1 : C.d0;
+    const uint32_t* cu = C.plane == 1 ? C.c1 : C.c0;
+    r.u = *reinterpret_cast<const int4*>(pu + e0);
+    r.cu = cu[k];
+    r.v = make_int4(0, 0, 0, 0);
+    r.cv = 0;
+    if (C.plane == 2) {
+        r.v = *reinterpret_cast<const int4*>(C.d1 + e0);
+        r.cv = C.c1[k];
+    }
+    return r;
+}
+__device__ __forceinline__ Seg combine_seg(const RawSeg& r) {
+    Seg s;
+    s.a.x = r.u.x + r.v.x; s.a.y = r.u.y + r.v.y; s.a.z = r.u.z + r.v.z; s.a.w = r.u.w + r.v.w;
+    s.carry = r.cu + r.cv;
     return s;
 }
 
@@ -135,17 +224,20 @@ __device__ __forceinline__ void for_each_depth(const Ctx& C, uint64_t gs, uint64
 }
 
 // Exclusive prefix over the threads of the workgroup of (count, sum); s_w* are LDS scratch of kWaves entries.
+// The 64-bit sums (< 2^44: at most 2^28 values below 2^10 per thread... in fact bin * count summed over a thread's
+// bins) are scanned as two 32-bit halves of 20 / 24 bits, so that neither wraps over 64 lanes: DPP only, no LDS.
 template <int kWaves>
 __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long tsum, uint32_t& pre,
                                                 unsigned long long& pre_sum, uint32_t* s_wc, unsigned long long* s_ws) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t c = tot;
-    unsigned long long s = tsum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t oc = __shfl_up(c, d);
-        unsigned long long os = __shfl_up(s, d);
-        if ((int)lane >= d) { c += oc; s += os; }
+    const uint32_t c = wave_inclusive_scan_dpp(tot);
+    const uint32_t lo = wave_inclusive_scan_dpp((uint32_t)tsum & 0xfffffu);
+    const uint32_t hi = wave_inclusive_scan_dpp((uint32_t)(tsum >> 20));
+    const unsigned long long s = ((unsigned long long)hi << 20) + lo;
+    if (kWaves == 1) {
+        pre = c - tot;
+        pre_sum = s - tsum;
+        return;
     }
     if (lane == 63) { s_wc[wave] = c; s_ws[wave] = s; }
     __syncthreads();
@@ -181,10 +273,11 @@ __device__ __forceinline__ double percentile_value(const PctRanks& q, uint32_t v
 }
 
 template <int kThreads, int kMaxFlank, int kInFlight>
-__global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, uint32_t first_rec) {
+__global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel(IntronTables T, const uint32_t* __restrict__ wg_off, uint32_t prof_slot) {
     constexpr int kWaves = kThreads / 64;
-    constexpr int kBinsPerThread = kBins / kThreads > 0 ? kBins / kThreads : 1;
-    __shared__ uint32_t s_cnt[kBins];
+    constexpr int kBinsPerThread = kBins / kThreads;
+    static_assert(kBinsPerThread >= 1 && kBinsPerThread <= 16, "a thread's bins must fit one DPP row");
+    __shared__ __align__(16) uint32_t s_cnt[kBins];
     __shared__ uint32_t s_win[2][kMaxFlank];               // depths of the two flank windows
     __shared__ uint32_t s_med[4];                          // per window: the two order statistics its median reads
     __shared__ uint32_t s_wc[kWaves];
@@ -193,41 +286,72 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
     __shared__ unsigned long long s_total, s_nz, s_acc;
     __shared__ uint32_t s_qval[kQueries];
     __shared__ unsigned long long s_qsum[kQueries];
-    __shared__ unsigned long long s_qrank[kQueries];
-    __shared__ uint32_t s_qneed[kQueries];
-    __shared__ uint32_t s_prem[3];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const IntronRec R = T.recs[first_rec + blockIdx.x];        // wave-uniform: scalar loads
+    const uint32_t k_begin = wg_off[blockIdx.x], k_end = wg_off[blockIdx.x + 1];
+    if (k_begin >= k_end) return;
+#ifdef STATS_PROF
+    unsigned long long prof_t = wall_clock64();
+    uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     Ctx C;
     C.d0 = T.diff;
     C.d1 = T.diff + T.plane_stride;
     C.c0 = T.carry;
     C.c1 = T.carry + T.plane_stride / kSeg;
-    const bool valid = R.valid != 0 && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
     C.plane = 2;
-    if (T.directionality != 0) C.plane = ((R.plus != 0) == (T.directionality > 0)) ? 1 : 0;
+
+    // ---- the header pipeline -------------------------------------------------------------------------------------
+    // Everything an intron needs before its first plane load is fetched while the workgroup still works on the
+    // introns before it: the record two introns ahead, the block descriptors and the row's counters one ahead.
+    // Vector loads on purpose (lane l holds dword l of the record; every wave keeps its own copy): they retire in
+    // order under vmcnt, so waiting for plane data never waits for anything younger, and no LDS wait drains them.
+    const uint32_t* __restrict__ recw = reinterpret_cast<const uint32_t*>(T.recs);
+    auto load_rec = [&](uint32_t k) -> uint32_t {
+        const uint32_t kc = k < k_end ? k : k_end - 1u;
+        return recw[(uint64_t)kc * (sizeof(IntronRec) / 4u) + (lane & 31u)];
+    };
+    auto load_hdr = [&](uint32_t rec, BlkRec& d, uint32_t& tc) {
+        const uint32_t blk_off = lane_u32(rec, 6), n_blk = lane_u32(rec, 7), flags = lane_u32(rec, 14);
+        d = T.blks[blk_off + (lane < n_blk ? lane : 0u)];              // the table ends with one spare entry
+        tc = 0;
+        // lanes 0..9: sp_cnt[sp_s], sp_cnt[sp_e], left_cnt[us], right_cnt[ue], known_cnt[kj], each for both strands
+        const uint32_t which = lane >> 1, half = lane & 1u;
+        int32_t ix = -1;
+        const uint32_t* base = T.sp_cnt;
+        uint64_t n = T.n_sp;
+        const int32_t sp_s = (int32_t)lane_u32(rec, 8), sp_e = (int32_t)lane_u32(rec, 9), us = (int32_t)lane_u32(rec, 10),
+                      ue = (int32_t)lane_u32(rec, 11), kj = (int32_t)lane_u32(rec, 12);
+        if (which == 0u) ix = sp_s;
+        else if (which == 1u) ix = sp_e;
+        else if (which == 2u) { ix = us; base = T.left_cnt; n = T.n_ustart; }
+        else if (which == 3u) { ix = ue; base = T.right_cnt; n = T.n_uend; }
+        else if (which == 4u) { ix = kj; base = T.known_cnt; n = T.n_kj; }
+        if ((flags & 1u) && !(T.ablate & 2u) && ix >= 0) tc = base[(uint64_t)half * n + (uint64_t)ix];
+    };
+    uint32_t recA = load_rec(k_begin), recB = load_rec(k_begin + 1u);
+    BlkRec dA;
+    uint32_t tcA;
+    load_hdr(recA, dA, tcA);
+
+    for (uint32_t kk = k_begin; kk < k_end; kk++) {
+    const uint32_t recC = load_rec(kk + 2u);
+    BlkRec dB;
+    uint32_t tcB;
+    load_hdr(recB, dB, tcB);
+
+    const uint64_t gS = lane_u64v(recA, 0), gE = lane_u64v(recA, 2);
+    const unsigned long long N = lane_u64v(recA, 4);
+    const uint32_t b0 = lane_u32(recA, 6), nb = lane_u32(recA, 7);
+    const int32_t r_kj = (int32_t)lane_u32(recA, 12);
+    const uint32_t r_row = lane_u32(recA, 13), r_flags = lane_u32(recA, 14), r_prem = lane_u32(recA, 15);
+    const uint32_t qneed = (r_flags >> 8) & 0xffu;
+    const bool r_valid = (r_flags & 1u) != 0;
+    const bool valid = r_valid && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
+    C.plane = 2;
+    if (T.directionality != 0) C.plane = (((r_flags & 2u) != 0) == (T.directionality > 0)) ? 1 : 0;
     const int plane = C.plane;
-
-    // The counters of the row's tail, fetched now (uniform addresses: they land in scalar registers while the depth
-    // pass runs).  They were finalised by the kernels before this one.
-    uint32_t spl = 0, spr = 0, jl = 0, jr = 0, je = 0;
-    if (R.valid != 0 && !(T.ablate & 2u)) {
-        auto both = [&](const uint32_t* cnt, uint64_t n, int32_t idx) -> uint32_t {
-            if (idx < 0) return 0u;
-            return plane == 2 ? cnt[idx] + cnt[n + (uint64_t)idx] : cnt[(uint64_t)plane * n + (uint64_t)idx];
-        };
-        spl = both(T.sp_cnt, T.n_sp, R.sp_s);
-        spr = both(T.sp_cnt, T.n_sp, R.sp_e);
-        jl = both(T.left_cnt, T.n_ustart, R.us);
-        jr = both(T.right_cnt, T.n_uend, R.ue);
-        je = both(T.known_cnt, T.n_kj, R.kj);      // (Start,End) is a ref-sj junction: its reads were counted in place
-    }
-
-    const uint32_t b0 = R.blk_off, nb = R.n_blk;
-    const unsigned long long N = R.measured;
-    const uint64_t gS = R.g_start, gE = R.g_end;
 
     // first / last flank_len nt of the intron, flank_offset nt inside it (full coordinates)
     uint64_t w0[2], w1[2];
@@ -240,10 +364,12 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
         w0[1] = gE - (fo + fl < ilen ? fo + fl : ilen);
     }
 
-    for (int k = tid; k < kBins; k += kThreads) s_cnt[k] = 0;
+    for (int k = tid; k < kBins / 4; k += kThreads) reinterpret_cast<uint4*>(s_cnt)[k] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; s_acc = 0; }
     if (tid < 4) s_med[tid] = 0;
+    if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
     __syncthreads();
+    PROF_MARK(0);
 
     // ---------------- pass A: histogram (clipped) + window capture ----------------
     // (total, non-zero count and maximum are read off the histogram afterwards)
@@ -266,7 +392,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
             // the parts of the two flank windows that fall inside it (every wave builds the same registers)
             const uint32_t nbc = nb - cb < kMaxBlk ? nb - cb : kMaxBlk;
             const bool has = lane < nbc;
-            const BlkRec br = T.blks[b0 + cb + (has ? lane : 0u)];
+            BlkRec br = dA;                                            // the first chunk came with the header
+            if (cb) br = T.blks[b0 + cb + (has ? lane : 0u)];
             const uint64_t d_bc = br.cstart;
             const uint32_t d_bl = has ? br.len : 0u;
             const uint32_t d_nseg = d_bl ? (uint32_t)((d_bc + d_bl - 1u) / kSeg - d_bc / kSeg + 1u) : 0u;
@@ -287,64 +414,99 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
             const uint32_t S = lane_u32(d_seg_end, 63u);
 
             for (uint32_t s0 = wave; s0 < S; s0 += kWaves * kInFlight) {
-                Seg sg[kInFlight];
+                RawSeg raw[kInFlight];
                 uint32_t sb[kInFlight];
                 uint64_t sk[kInFlight];
+                // addresses first (ballots and readlanes), then nothing but loads, then the work: the loads of all
+                // kInFlight segments are outstanding together
 #pragma unroll
                 for (int j = 0; j < kInFlight; j++) {
                     const uint32_t s = s0 + j * kWaves;
                     const uint32_t sc = s < S ? s : S - 1u;           // past the end: load the last segment again, unused
                     sb[j] = (uint32_t)__popcll(__ballot(d_seg_end <= sc));        // blocks that end before segment sc
                     sk[j] = lane_u64(d_bc, sb[j]) / kSeg + (sc - lane_u32(d_seg_start, sb[j]));
-                    sg[j] = load_seg(C, sk[j], lane);
+                }
+#pragma unroll
+                for (int j = 0; j < kInFlight; j++) {
+                    if (T.ablate & 8u) { raw[j].u = raw[j].v = make_int4(0, 0, 0, 0); raw[j].cu = raw[j].cv = (uint32_t)sk[j] & 3u; continue; }   // diagnostic: no loads
+                    raw[j] = issue_seg(C, sk[j], lane);
                 }
 #pragma unroll
                 for (int j = 0; j < kInFlight; j++) {
                     if (s0 + j * kWaves >= S) continue;                // wave-uniform
+                    const Seg sgj = combine_seg(raw[j]);
+                    if (T.ablate & 4u) { if (sgj.a.x + sgj.a.y + sgj.a.z + sgj.a.w + (int)sgj.carry == 0x7fffffff) ovf = true; continue; }     // diagnostic: loads only
+                    // everything wave-uniform about the segment, relative to its first position (scalar unit): the
+                    // measured part [lo, hi) and the parts of the two flank windows, [wl, wh) with element index
+                    // wat + (p - wa) in the window buffer
                     const uint32_t b = sb[j];
-                    const uint64_t bc = lane_u64(d_bc, b), be_c = bc + lane_u32(d_bl, b);
-                    const uint32_t wn0 = lane_u32(d_wn[0], b), wn1 = lane_u32(d_wn[1], b);
-                    const uint64_t ws0 = wn0 ? bc + lane_u32(d_wlo[0], b) : 0ull, we0 = ws0 + wn0;
-                    const uint64_t ws1 = wn1 ? bc + lane_u32(d_wlo[1], b) : 0ull, we1 = ws1 + wn1;
-                    const uint32_t at0 = lane_u32(d_wat[0], b), at1 = lane_u32(d_wat[1], b);
-                    emit_seg(sg[j], sk[j], lane, [&](uint64_t seg0, uint64_t e0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-                        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
-                        const bool inner = seg0 >= bc && seg0 + kSeg <= be_c &&                         // whole segment measured
-                                           !(seg0 < we0 && seg0 + kSeg > ws0) && !(seg0 < we1 && seg0 + kSeg > ws1);
-                        const bool flat = v0 == first && v1 == first && v2 == first && v3 == first;
-                        if (inner && __ballot(flat) == ~0ull) {
-                            // depth is piecewise constant: most segments hold one value 256 times -> one LDS atomic
-                            if (lane == 0) { if (first < (uint32_t)kBins) atomicAdd(&s_cnt[first], (uint32_t)kSeg); else ovf = true; }
-                            return;
-                        }
+                    const uint64_t seg0 = sk[j] * kSeg;
+                    const int64_t rel = (int64_t)(lane_u64(d_bc, b) - seg0);           // block start - segment start: < 256
+                    const int64_t rel_end = rel + (int64_t)lane_u32(d_bl, b);
+                    const int32_t lo = rel > 0 ? (int32_t)rel : 0;
+                    const int32_t hi = rel_end < (int64_t)kSeg ? (int32_t)rel_end : kSeg;
+                    int32_t wa[2], wl[2], wh[2];
+                    uint32_t wat[2];
+#pragma unroll
+                    for (int wi = 0; wi < 2; wi++) {
+                        const uint32_t wn = lane_u32(d_wn[wi], b);
+                        int64_t a = rel + (int64_t)lane_u32(d_wlo[wi], b);
+                        a = a < -(int64_t)(1 << 20) ? -(int64_t)(1 << 20) : a;         // far before the segment: empty below
+                        wa[wi] = (int32_t)a;
+                        const int64_t e = a + (int64_t)wn;
+                        wl[wi] = a > 0 ? (int32_t)a : 0;
+                        wh[wi] = wn == 0u ? 0 : (e < (int64_t)kSeg ? (int32_t)e : kSeg);
+                        wat[wi] = lane_u32(d_wat[wi], b);
+                    }
+                    const bool win_here = wl[0] < wh[0] || wl[1] < wh[1];
+                    // depths of this lane's four positions
+                    const uint32_t t = (uint32_t)(sgj.a.x + sgj.a.y + sgj.a.z + sgj.a.w);
+                    const uint32_t incl = wave_inclusive_scan_dpp(t);
+                    const uint32_t v0 = sgj.carry + incl - t + (uint32_t)sgj.a.x;
+                    const uint32_t v1 = v0 + (uint32_t)sgj.a.y, v2 = v1 + (uint32_t)sgj.a.z, v3 = v2 + (uint32_t)sgj.a.w;
+                    const int32_t p0 = (int32_t)(lane * 4u);
+                    // Depth is piecewise constant.  A lane whose four positions are all measured and equal ("full") is
+                    // one histogram entry of weight 4; full lanes are merged per value by the wave (two rounds of
+                    // leader election: a segment rarely holds more than two frequent depths), the rest add on their own.
+                    const bool full = v1 == v0 && v2 == v0 && v3 == v0 && p0 >= lo && p0 + 3 < hi;
+                    uint64_t todo = __ballot(full);
+                    bool pending = full;
+#pragma unroll
+                    for (int round = 0; round < 2; round++) {
+                        if (!todo) break;                                  // wave-uniform
+                        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                        const uint32_t lead = lane_u32(v0, leader);
+                        const uint64_t same = __ballot(pending && v0 == lead);
+                        if (lead < (uint32_t)kBins) { if (lane == leader) atomicAdd(&s_cnt[lead], 4u * (uint32_t)__popcll(same)); }
+                        else ovf = true;
+                        pending = pending && v0 != lead;
+                        todo &= ~same;
+                    }
+                    if (todo) {
+                        if (pending) { if (v0 < (uint32_t)kBins) atomicAdd(&s_cnt[v0], 4u); else ovf = true; }
+                    }
+                    if (__ballot(!full)) {
+                        // lanes on a depth change or on the edge of the measured part: position by position
                         const uint32_t vv[4] = {v0, v1, v2, v3};
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const uint64_t x = e0 + q;
-                            const uint32_t v = vv[q];
-                            const bool ok = x >= bc && x < be_c;
-                            // wave-aggregated histogram update: lanes that share the first valid lane's value add once
-                            const uint64_t act = __ballot(ok);
-                            if (!act) continue;
-                            const uint32_t lead = __shfl(v, __ffsll((long long)act) - 1);
-                            const uint64_t same = __ballot(ok && v == lead);
-                            if (ok) {
-                                if (v == lead) {
-                                    if (lane == (uint32_t)(__ffsll((long long)same) - 1)) {
-                                        if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], (uint32_t)__popcll(same)); else ovf = true;
-                                    }
-                                } else {
-                                    if (v < (uint32_t)kBins) atomicAdd(&s_cnt[v], 1u); else ovf = true;
-                                }
-                                if (x >= ws0 && x < we0) s_win[0][at0 + (uint32_t)(x - ws0)] = v;
-                                if (x >= ws1 && x < we1) s_win[1][at1 + (uint32_t)(x - ws1)] = v;
-                            }
+                            if (!full && p0 + q >= lo && p0 + q < hi) { if (vv[q] < (uint32_t)kBins) atomicAdd(&s_cnt[vv[q]], 1u); else ovf = true; }
                         }
-                    });
+                    }
+                    if (win_here) {
+                        const uint32_t vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int32_t pq = p0 + q;
+                            if (pq >= wl[0] && pq < wh[0]) s_win[0][wat[0] + (uint32_t)(pq - wa[0])] = vv[q];
+                            if (pq >= wl[1] && pq < wh[1]) s_win[1][wat[1] + (uint32_t)(pq - wa[1])] = vv[q];
+                        }
+                    }
                 }
             }
         }
         if (ovf) s_overflow = 1;
+        PROF_MARK(1);
     } else {
         // all-zero depth: N zeros in the histogram, all-zero windows of the right size
         if (tid == 0) s_cnt[0] = (uint32_t)N;
@@ -366,6 +528,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
         }
     }
     __syncthreads();
+    PROF_MARK(2);
     const bool overflow = s_overflow != 0;
     if (overflow) {
         // depth beyond the single-level histogram somewhere: maximum, total and non-zero count by a pass of their own
@@ -393,7 +556,22 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
     PctRanks fq[2];
     fq[0] = percentile_ranks(nwin[0], 50u, T.pct_interpolate != 0);
     fq[1] = percentile_ranks(nwin[1], 50u, T.pct_interpolate != 0);
-    {
+    if (nwin[0] <= 64u && nwin[1] <= 64u) {
+        // a window per wave, an element per lane: the two order statistics by radix select over ballots
+        const int wi1_wave = kWaves > 1 ? 1 : 0;
+#pragma unroll
+        for (int wi = 0; wi < 2; wi++) {
+            if ((int)wave != (wi ? wi1_wave : 0)) continue;
+            const uint32_t n = nwin[wi];
+            if (n == 0u) continue;
+            const uint32_t v = lane < n ? s_win[wi][lane] : 0u;
+            const uint64_t cand = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+            const int nbits = 32 - __clz((int)(wave_or_dpp(v) | 1u));
+            const uint32_t va = wave_kth(v, cand, (uint32_t)fq[wi].ra, nbits);
+            const uint32_t vb = fq[wi].need_b ? wave_kth(v, cand, (uint32_t)fq[wi].rb, nbits) : 0u;
+            if (lane == 0) { s_med[2 * wi] = va; s_med[2 * wi + 1] = vb; }
+        }
+    } else {
         const uint32_t n0 = nwin[0], n1 = nwin[1];
         for (uint32_t e = tid; e < n0 + n1; e += kThreads) {
             const int wi = e >= n0 ? 1 : 0;
@@ -415,25 +593,12 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
             }
         }
     }
+    PROF_MARK(3);
 
     // ---------------- the rank queries ----------------
-    // q0,q1: sums below ranks lo / hi of the trimmed mean; q2..q7: values for p25, p50, p75 (ranks k-1 and k)
-    const unsigned long long skip = N * (unsigned long long)(100u - T.trim_centre_pct) / 200ull;
-    const unsigned long long lo = skip, hi = N - skip;
-    if (tid == 0) {
-        s_qrank[0] = lo; s_qneed[0] = (N > 0 && lo > 0 && lo < N) ? 1u : 0u;
-        s_qrank[1] = hi; s_qneed[1] = (N > 0 && hi > 0 && hi < N) ? 1u : 0u;
-        const uint32_t pcts[3] = {25u, 50u, 75u};
-        for (int p = 0; p < 3; p++) {
-            const PctRanks q = percentile_ranks(N, pcts[p], T.pct_interpolate != 0);
-            s_qrank[2 + 2 * p] = q.ra; s_qneed[2 + 2 * p] = q.need_a ? 1u : 0u;
-            s_qrank[3 + 2 * p] = q.rb; s_qneed[3 + 2 * p] = q.need_b ? 1u : 0u;
-            s_prem[p] = q.rem;
-        }
-    }
-    if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
-    __syncthreads();
-
+    // q0,q1: sums below ranks lo / hi of the trimmed mean; q2..q7: values for p25, p50, p75 (ranks k-1 and k);
+    // the ranks were worked out by the host (kernels.h: stats_queries) and travel in the record
+    const unsigned long long lo = lane_u32(recA, 16), hi = lane_u32(recA, 17);
     if (N > 0 && !overflow) {
         // single level: bins are the depths themselves
         uint32_t c[kBinsPerThread];
@@ -449,19 +614,27 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
         unsigned long long pre_sum;
         block_excl_scan<kWaves>(tot, tsum, pre, pre_sum, s_wc, s_ws);
         if (tid == kThreads - 1) s_total = pre_sum + tsum;       // sum of all depths
-#pragma unroll
+        // the thread whose bins hold rank r is found by a ballot; then the lanes of its wave take one of its bins each
         for (int q = 0; q < kQueries; q++) {
-            if (!s_qneed[q]) continue;
-            const unsigned long long r = s_qrank[q];
-            if (r >= pre && r < (unsigned long long)pre + tot) {
-                unsigned long long run = pre, s = pre_sum;
-#pragma unroll
-                for (int j = 0; j < kBinsPerThread; j++) {
-                    const unsigned long long bin = (unsigned long long)(tid * kBinsPerThread + j);
-                    if (r < run + c[j]) { s_qval[q] = (uint32_t)bin; s_qsum[q] = s + bin * (r - run); break; }
-                    run += c[j];
-                    s += bin * c[j];
-                }
+            if (!((qneed >> q) & 1u)) continue;                                    // wave-uniform
+            const uint32_t r = lane_u32(recA, 16u + q);
+            const uint64_t own = __ballot(r >= pre && r - pre < tot);
+            if (!own) continue;                                                    // another wave's bins
+            const uint32_t ol = (uint32_t)__ffsll((long long)own) - 1u;
+            const uint32_t rr = r - lane_u32(pre, ol);                             // rank among the owner's bins
+            const unsigned long long o_psum = lane_u64(pre_sum, ol);
+            const uint32_t base = (wave * 64u + ol) * (uint32_t)kBinsPerThread;    // the owner's first bin
+            const bool mine = lane < (uint32_t)kBinsPerThread;
+            const uint32_t cj = mine ? s_cnt[base + lane] : 0u;
+            const uint32_t wj = cj * lane;                                         // (bin - base) * count: N < 2^28 (host check)
+            const uint32_t ic = row_inclusive_scan_dpp(cj), iw = row_inclusive_scan_dpp(wj);
+            const uint64_t hit = __ballot(mine && rr >= ic - cj && rr < ic);       // exactly one lane
+            const uint32_t hl = (uint32_t)__ffsll((long long)hit) - 1u;
+            const uint32_t ex_c = lane_u32(ic - cj, hl), ex_w = lane_u32(iw - wj, hl);
+            const unsigned long long bin = base + hl;
+            if (lane == 0) {
+                s_qval[q] = (uint32_t)bin;
+                s_qsum[q] = o_psum + (unsigned long long)base * ex_c + ex_w + bin * (unsigned long long)(rr - ex_c);
             }
         }
         __syncthreads();
@@ -472,8 +645,8 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
         int levels = (bits + kBinBits - 1) / kBinBits;
         if (levels < 1) levels = 1;
         for (int q = 0; q < kQueries; q++) {
-            if (!s_qneed[q]) continue;                     // uniform across the block
-            unsigned long long r = s_qrank[q];
+            if (!((qneed >> q) & 1u)) continue;            // uniform across the block
+            unsigned long long r = lane_u32(recA, 16u + q);
             uint32_t prefix = 0;
             for (int lv = 0; lv < levels; lv++) {
                 const int shift = kBinBits * (levels - 1 - lv);
@@ -534,8 +707,16 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
     } else {
         __syncthreads();
     }
+    PROF_MARK(4);
 
     // ---------------- the row ----------------
+    // the counters that came with the header: lanes 2w, 2w+1 = strand 0 / 1 of counter w
+    auto pick = [&](uint32_t w) -> uint32_t {
+        const uint32_t a = lane_u32(tcA, 2u * w), b = lane_u32(tcA, 2u * w + 1u);
+        return plane == 2 ? a + b : (plane == 1 ? b : a);
+    };
+    const uint32_t spl = pick(0), spr = pick(1), jl = pick(2), jr = pick(3);
+    uint32_t je = pick(4);                  // (Start,End) is a ref-sj junction: its reads were counted in place
     if (tid == 0) {
         const double flank0 = percentile_value(fq[0], s_med[0], s_med[1]);
         const double flank1 = percentile_value(fq[1], s_med[2], s_med[3]);
@@ -549,11 +730,11 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const double vk = (double)s_qval[2 + 2 * p];
-                if (s_qneed[3 + 2 * p]) pv[p] = vk + ((double)s_prem[p] / 100.0) * ((double)s_qval[3 + 2 * p] - vk);
+                if ((qneed >> (3 + 2 * p)) & 1u) pv[p] = vk + ((double)((r_prem >> (8 * p)) & 0xffu) / 100.0) * ((double)s_qval[3 + 2 * p] - vk);
                 else pv[p] = vk;
             }
         }
-        if (R.valid != 0 && !(T.ablate & 2u) && R.kj < 0) {
+        if (r_valid && !(T.ablate & 2u) && r_kj < 0) {
             // (Start,End) is not in ref-sj: look it up among the novel junctions
             const uint64_t span = gE - gS;
             if (span < (1ull << kJuncSpanBits) && gS < kJuncMaxGlobal && T.n_unique > 0) {
@@ -582,7 +763,7 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
         else if (maxflank > depth * T.warn_nonuniform_rel + T.warn_nonuniform_abs) warn = 4;
         else warn = 0;
         const uint64_t n = T.n_intron;
-        const uint64_t i = R.row;
+        const uint64_t i = r_row;
         T.out_f64[0 * n + i] = coverage;
         T.out_f64[1 * n + i] = depth;
         T.out_f64[2 * n + i] = pv[0];
@@ -598,17 +779,43 @@ __global__ __launch_bounds__(kThreads) void intron_stats_kernel(IntronTables T, 
         T.out_u32[4 * n + i] = je;
         T.out_u32[5 * n + i] = warn;
     }
+    __syncthreads();            // the row has read the LDS results: the next intron may clear them
+    PROF_MARK(5);
+    recA = recB; recB = recC; dA = dB; tcA = tcB;
+    }
+#ifdef STATS_PROF
+    if (tid == 0 && prof_slot + blockIdx.x < kProfMax) {
+        for (int k = 0; k < 6; k++) g_prof[prof_slot + blockIdx.x][k] = prof_acc[k];
+        g_prof[prof_slot + blockIdx.x][6] = k_end - k_begin;
+    }
+#endif
 }
 
 }   // namespace
 
-// T.recs is sorted by size class (kernels.h: StatsClasses), longest intron first inside a class; every class is one
-// launch with its own workgroup size.  The small workgroups keep their flank windows in a 64-entry LDS buffer: the
-// host puts every intron into the 256-thread class when flank_len is larger.
+// T.recs is laid out by size class (kernels.h: StatsClasses) and, inside a class, by workgroup: workgroup w of class c
+// walks records [wg_off[c][w], wg_off[c][w + 1]) (the host balanced the lists).  The 64-thread class keeps its flank
+// windows in a 64-entry LDS buffer: the host puts every intron into the 256-thread class when flank_len is larger.
 void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s) {
-    if (K.count[0]) hipLaunchKernelGGL((intron_stats_kernel<1024, kStatsMaxFlank, 4>), dim3(K.count[0]), dim3(1024), 0, s, T, K.first[0]);
-    if (K.count[1]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, 4>), dim3(K.count[1]), dim3(256), 0, s, T, K.first[1]);
-    if (K.count[2]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, 4>), dim3(K.count[2]), dim3(64), 0, s, T, K.first[2]);
+    if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
+    if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+#ifdef STATS_PROF
+    {
+        static std::vector<uint32_t> h((size_t)kProfMax * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_prof), h.size() * 4);
+        uint32_t at = 0;
+        for (int c = 0; c < 2; c++) {
+            double a[8] = {0};
+            for (uint32_t k = at; k < at + K.n_wg[c] && k < kProfMax; k++)
+                for (int j = 0; j < 7; j++) a[j] += h[(size_t)k * 8 + j];
+            at += K.n_wg[c];
+            if (a[6] > 0)
+                fprintf(stderr, "stats_prof class %d n=%.0f wgs=%u ticks/intron: zero %.0f segments %.0f sync %.0f medians %.0f queries %.0f row+sync %.0f\n", c, a[6], K.n_wg[c],
+                        a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6], a[5] / a[6]);
+        }
+    }
+#endif
 }
 
 }   // namespace dev
