@@ -233,8 +233,9 @@ def main():
     alg = {
         # input stream (13 B/fragment + 4 B CSR offset, 9 B/block) + two 4-byte difference-array targets per block
         "count_ms": n_frag * 17 + n_blk * 9 + n_blk * 2 * 4,
-        # depth carries: ONE read of the planes (4 B per kept position and strand); depth is never written back
-        "scan_ms": G * 2 * 4,
+        # depth carries: the count kernel keeps the per-256-position segment sums next to the planes, so finalize only
+        # scans them (read + write of 4 B per segment and strand); the planes are not read again, depth is never written
+        "scan_ms": (G // 256) * 2 * 4 * 2,
         # statistics: 4 B per measured intron base and strand (both strands for the non-directional table)
         "stats_ms": lay["measured_positions"] * 2 * 4,
     }
@@ -248,12 +249,12 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_summary.json")))
-        kname = {"count_ms": "count_kernel", "scan_ms": "segment_sums_kernel", "stats_ms": "intron_stats_kernel"}[dom]
+        kname = {"count_ms": "count_kernel", "scan_ms": "scan_tiles_kernel", "stats_ms": "intron_stats_kernel"}[dom]
         if world == 1 and args.genome == "grch38" and args.pairs == 50_000_000 and not args.stranded and args.order == "sorted":
             traffic = pmc["kernels"][kname]["hbm_bytes_corrected"]
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "segment_sums_kernel", "stats_ms": "intron_stats_kernel"}[dom],
+    roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "scan_tiles_kernel", "stats_ms": "intron_stats_kernel"}[dom],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "per_kernel": kernels, "layout": lay}
 

@@ -93,6 +93,28 @@ struct Lds {
     uint32_t nq_n, wmax;
 };
 
+// Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
+// (row_sum), lane 63 with the wave's (wave_sum).
+__device__ __forceinline__ int row_sum_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    return v;
+}
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+    v = row_sum_dpp(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// The sum of every 256-position segment of the planes is kept next to them (seg_sum; its exclusive scan is the depth
+// carry of stats.hip), so that finalize does not have to read the planes once more just to add them up.
+__device__ __forceinline__ void seg_add(const CountTables& T, uint32_t dir, uint64_t c, int v) {
+    __hip_atomic_fetch_add(T.seg_sum + (uint64_t)dir * (T.plane_stride >> kSegShift) + (c >> kSegShift), (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ uint64_t plane_of(const CountTables& T, uint32_t m, uint64_t g) {
     if (!T.pmap) return g;
     const uint64_t c = (uint64_t)(m >> 1) << kBucketShift;
@@ -111,6 +133,7 @@ __device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsign
     }
 #ifdef K_NOLINES
     __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seg_add(T, dir, c, v);
     return;
 #endif
     const uint32_t want = (uint32_t)(c >> 4) * 2u + dir;
@@ -118,7 +141,10 @@ __device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsign
     uint32_t tag = S.ltag[slot];
     if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ltag[slot], kEmpty, want); tag = old == kEmpty ? want : old; }
     if (tag == want) atomicAdd(&S.lcnt[slot][c & 15u], v);
-    else __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+        __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seg_add(T, dir, c, v);
+    }
 }
 
 // n reads of strand dir on known junction idx (difference events at plane positions cl / cr): the chunk's LDS
@@ -496,27 +522,35 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         // 3b. line cache and window: consecutive lanes = consecutive positions, so that a wave's atomics fall into
         //     whole 64-byte lines (the memory-side atomic unit works per line)
         const uint32_t wtop = S.wmax;
+        static_assert((kLines * 16u) % kThreads == 0u && kWin % kThreads == 0u, "the flush loops run with whole waves (DPP sums)");
         for (uint32_t e = tid; e < kLines * 16u; e += kThreads) {
-            const uint32_t slot = e >> 4, cell = e & 15u;
+            const uint32_t slot = e >> 4, cell = e & 15u;               // a 16-lane row = one line = inside one segment
             const uint32_t tag = S.ltag[slot];
-            if (tag != kEmpty) {
-                const int32_t v = S.lcnt[slot][cell];
-                if (v) {
-                    if (!(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + (uint64_t)(tag & 1u) * T.plane_stride + ((uint64_t)(tag >> 1) << 4) + cell, v,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    S.lcnt[slot][cell] = 0;
-                }
-            }
-        }
-        for (uint32_t e = tid; e <= wtop; e += kThreads) {
-            const int32_t v = S.tile[e];
+            const int32_t v = tag != kEmpty ? S.lcnt[slot][cell] : 0;
+            const uint64_t c = ((uint64_t)(tag >> 1) << 4) + cell;
             if (v) {
-                const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
-                const int32_t v1 = (v - v0) >> 16;
+                if (!(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + (uint64_t)(tag & 1u) * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S.lcnt[slot][cell] = 0;
+            }
+            const int32_t line_sum = row_sum_dpp(v);
+            if (cell == 15u && line_sum) seg_add(T, tag & 1u, c, line_sum);
+        }
+        for (uint32_t e0 = 0; e0 <= wtop; e0 += kThreads) {
+            const uint32_t e = e0 + tid;                                // < kWin: the window is a multiple of the workgroup
+            const int32_t v = S.tile[e];
+            const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
+            const int32_t v1 = (v - v0) >> 16;
+            if (v) {
                 int32_t* g = T.diff + win + e;
                 if (v0 && !(T.ablate & 256u)) __hip_atomic_fetch_add(g, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v1 && !(T.ablate & 256u)) __hip_atomic_fetch_add(g + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 S.tile[e] = 0;
+            }
+            // the window starts on a multiple of 64: a wave's 64 positions share one segment
+            const int32_t s0 = wave_sum_dpp(v0), s1 = wave_sum_dpp(v1);
+            if (lane == 63u) {
+                if (s0) seg_add(T, 0u, win + e, s0);
+                if (s1) seg_add(T, 1u, win + e, s1);
             }
         }
         __syncthreads();

@@ -92,6 +92,7 @@ struct irf_ctx {
 
     // ---- device state ----
     DevBuf<int32_t> d_diff;
+    DevBuf<uint32_t> d_seg_sum;                  // [2][plane_stride/256] sum of each segment of d_diff (count kernel)
     DevBuf<uint32_t> d_carry;                    // [2][plane_stride/256] depth before each segment (after finalize)
     DevBuf<uint64_t> d_chr_base;
     DevBuf<uint32_t> d_chr_len;
@@ -106,7 +107,8 @@ struct irf_ctx {
     DevBuf<uint64_t> d_junc_a, d_junc_b;
     DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
     DevBuf<uint32_t> d_err;
-    DevBuf<uint32_t> d_ws;                       // scan / radix workspace
+    DevBuf<uint32_t> d_ws;                       // workspace of the carry scan
+    DevBuf<uint32_t> d_ws_sort;                  // workspace of the junction radix sort / compaction
     DevBuf<uint32_t> d_flags, d_uidx, d_ustart, d_ucount;
     DevBuf<uint64_t> d_ukeys;
     uint64_t n_unique = 0, n_events = 0;
@@ -318,6 +320,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     {
         const uint64_t n_seg = 2 * plane_stride / dev::kDepthSegment;
         hipError_t e = d_carry.reserve(n_seg);
+        if (e == hipSuccess) e = d_seg_sum.reserve(n_seg);
         if (e == hipSuccess) e = d_ws.reserve(dev::scan_workspace_elems(n_seg));
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth carries / scan workspace failed");
     }
@@ -577,7 +580,10 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
 
 int irf_ctx::zero_counters() {
     HIP_TRY(hipSetDevice(device));
+    // (clearing a second set of planes on a side stream under the next sample's count kernel was tried: the count
+    //  kernel slows down by exactly the time of the memset, so the planes are cleared in line)
     if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
+    if (plane_stride) HIP_TRY(hipMemsetAsync(d_seg_sum.p, 0, 2 * plane_stride / dev::kDepthSegment * sizeof(uint32_t), stream));
     if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
     if (n_roi) HIP_TRY(hipMemsetAsync(d_roi_cnt.p, 0, (size_t)n_roi * 2 * sizeof(uint32_t), stream));
     if (n_sp) HIP_TRY(hipMemsetAsync(d_sp_cnt.p, 0, (size_t)n_sp * 2 * sizeof(uint32_t), stream));
@@ -605,7 +611,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.plane_stride = plane_stride; T.full_size = full_size; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
     T.junc_capacity = d_junc_a.cap;
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
-    T.diff = d_diff.p; T.chr_cnt = d_chr_cnt.p;
+    T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p; T.roi_bucket = d_roi_bucket.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
     T.sp_gpos = d_sp_gpos.p; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
@@ -747,6 +753,23 @@ int irf_ctx::finalize() {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize(copy_stream));
     HIP_TRY(hipEventRecord(ev[0], stream));
+    // Everything that needs no answer from the device is queued before the first synchronisation: the depth carries
+    // (exclusive scan of the per-segment sums the count kernel kept next to the planes) and the known-junction
+    // lookups with the strandedness vote (known junctions were counted in place; novel ones never vote).
+    if (getenv("IRF_RESCAN_PLANES")) dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_seg_sum.p, stream);     // diagnostic: recompute the sums from the planes
+    dev::launch_exclusive_scan_u32(d_seg_sum.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));
+    if (n_ue) HIP_TRY(hipMemsetAsync(d_right_cnt.p, 0, (size_t)n_ue * 2 * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_scalars.p + 3, 0, 2 * sizeof(unsigned long long), stream));
+    dev::JuncLookupTables J;
+    memset(&J, 0, sizeof J);
+    J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
+    J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
+    J.known_keys = d_known_keys.p; J.known_kjidx = d_known_kjidx.p; J.known_dir = d_known_dir.p;
+    J.n_known = n_known_dev; J.n_kj = n_kj; J.known_cnt = d_known_cnt.p;
+    J.dir_votes = d_scalars.p + 3;
+    dev::launch_known_lookups(J, stream);
     // ---- junction events -> sorted unique table ----
     unsigned long long scal[8];
     uint32_t errf = 0;
@@ -759,13 +782,15 @@ int irf_ctx::finalize() {
         return fail(errf & dev::ERR_JUNC_CAPACITY ? IRF_E_STATE : IRF_E_RANGE, m);
     }
     n_events = scal[0];
+    votes[0] = scal[3]; votes[1] = scal[4];
     if (n_events > 0xffffffffull) return fail(IRF_E_RANGE, "more than 2^32-1 junction events");
     n_unique = 0;
     d_sorted = d_junc_a.p;
     if (n_events) {
         if (d_junc_b.reserve(d_junc_a.cap) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort buffer failed");
-        uint64_t ws_need = std::max(dev::radix_workspace_elems(n_events), dev::scan_workspace_elems(std::max<uint64_t>(n_events, 2 * plane_stride / dev::kDepthSegment)));
-        if (ws_need > d_ws.cap) { if (d_ws.reserve(ws_need) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort workspace failed"); }
+        uint64_t ws_need = std::max(dev::radix_workspace_elems(n_events), dev::scan_workspace_elems(n_events));
+        // the sort has its own workspace: d_ws still holds nothing the statistics need, but keep the two apart
+        if (ws_need > d_ws_sort.cap) { if (d_ws_sort.reserve(ws_need) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort workspace failed"); }
         unsigned long long init[2] = {0ull, ~0ull};
         HIP_TRY(hipMemcpyAsync(d_scalars.p + 1, init, sizeof init, hipMemcpyHostToDevice, stream));
         dev::launch_key_bits(d_junc_a.p, n_events, d_scalars.p + 1, stream);
@@ -777,14 +802,14 @@ int irf_ctx::finalize() {
         uint64_t* dst = d_junc_b.p;
         for (int shift = 0; shift < 64; shift += 8) {
             if (((varying >> shift) & 0xffull) == 0) continue;     // digit identical in every key
-            dev::launch_radix_pass(src, dst, n_events, shift, d_ws.p, stream);
+            dev::launch_radix_pass(src, dst, n_events, shift, d_ws_sort.p, stream);
             std::swap(src, dst);
         }
         d_sorted = src;
         if (d_flags.reserve(n_events) != hipSuccess || d_uidx.reserve(n_events) != hipSuccess)
             return fail(IRF_E_NOMEM, "hipMalloc of the junction compaction buffers failed");
         dev::launch_head_flags(src, n_events, d_flags.p, stream);
-        dev::launch_exclusive_scan_u32(d_flags.p, d_uidx.p, n_events, d_ws.p, stream);
+        dev::launch_exclusive_scan_u32(d_flags.p, d_uidx.p, n_events, d_ws_sort.p, stream);
         uint32_t last[2];
         HIP_TRY(hipMemcpyAsync(&last[0], d_uidx.p + (n_events - 1), 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&last[1], d_flags.p + (n_events - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -794,31 +819,11 @@ int irf_ctx::finalize() {
             return fail(IRF_E_NOMEM, "hipMalloc of the junction table failed");
         dev::launch_unique_runs(src, d_flags.p, d_uidx.p, n_events, d_ukeys.p, d_ustart.p, stream);
         dev::launch_run_lengths(d_ustart.p, n_unique, n_events, d_ucount.p, stream);
-    }
-    // ---- SpliceLeft / SpliceRight per intron boundary, directionality vote ----
-    if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));
-    if (n_ue) HIP_TRY(hipMemsetAsync(d_right_cnt.p, 0, (size_t)n_ue * 2 * 4, stream));
-    HIP_TRY(hipMemsetAsync(d_scalars.p + 3, 0, 2 * sizeof(unsigned long long), stream));
-    {
-        dev::JuncLookupTables J;
-        memset(&J, 0, sizeof J);
+        // ---- SpliceLeft / SpliceRight contributions of the novel junctions ----
         J.ukeys = d_ukeys.p; J.ucount = d_ucount.p; J.n_unique = n_unique;
-        J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
-        J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
-        J.known_keys = d_known_keys.p; J.known_kjidx = d_known_kjidx.p; J.known_dir = d_known_dir.p;
-        J.n_known = n_known_dev; J.n_kj = n_kj; J.known_cnt = d_known_cnt.p;
-        J.dir_votes = d_scalars.p + 3;
         dev::launch_junction_lookups(J, stream);
-        dev::launch_known_lookups(J, stream);
     }
-    votes[0] = votes[1] = 0;
-    HIP_TRY(hipMemcpyAsync(votes, d_scalars.p + 3, sizeof votes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(ev[1], stream));
-    // ---- depth: one read of the difference planes -> per-segment sums -> carries (exclusive scan, in place) ----
-    dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_carry.p, stream);
-    dev::launch_exclusive_scan_u32(d_carry.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[2], stream));
-    HIP_TRY(hipStreamSynchronize(stream));
     // JunctionCount::Directional() (OQ-5)
     directionality = 0;
     if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
@@ -836,8 +841,8 @@ int irf_ctx::finalize() {
         if (hipEventElapsedTime(&ms, count_events[i].first, count_events[i].second) == hipSuccess) timing.count_ms += ms;
     }
     timing.n_count_launches = (uint32_t)count_events_used;
-    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) timing.junction_ms = ms;
-    if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) timing.scan_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) timing.scan_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) timing.junction_ms = ms;
     if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.stats_ms = ms;
     timing.table_ms = 0;       // the IR rows are written by the statistics kernel itself
     if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) timing.total_finalize_ms = ms;

@@ -16,6 +16,7 @@ namespace dev {
 constexpr int kJuncSpanBits = 28;
 constexpr int kJuncLeftShift = kJuncSpanBits + 1;
 constexpr uint64_t kJuncMaxGlobal = 1ull << 34;
+constexpr int kSegShift = 8;        // 256-position segments of the planes: one sum / depth carry each (kDepthSegment)
 constexpr int kBucketShift = 9;     // 512-position buckets of the full coordinate space (point / junction indices, plane map)
 
 // Plane map.  Only the buckets that hold measured intron bases are kept in the difference planes (about a third of
@@ -59,6 +60,7 @@ struct CountTables {
     const uint32_t* chr_len;   // [n_chr]
     const uint8_t* chr_owned;  // [n_chr]
     int32_t* diff;             // [2][plane_stride]  +1 at block start, -1 at block end
+    uint32_t* seg_sum;         // [2][plane_stride >> kSegShift]  sum of every 256-position segment of diff
     uint32_t* chr_cnt;         // [n_chr][2]
     // ROIs of owned chromosomes sorted by end, in full coordinates, + bucket index on the end
     const uint64_t* roi_gstart;
