@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--stranded", type=int, default=0)
     ap.add_argument("--order", choices=["sorted", "random"], default="sorted")
     ap.add_argument("--genome", choices=["grch38", "chr22", "toy"], default="grch38")
-    ap.add_argument("--cpu-pairs", type=int, default=2_000_000, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=50_000_000, help="size of the CPU-baseline sample (0 = skip); the default is the whole workload: about 10-20 s on one core")
     ap.add_argument("--threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "8")))
     ap.add_argument("--no-decode-bench", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -247,11 +247,12 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command (profiles/README.md);
     # bench.py itself cannot collect hardware counters
     traffic = None
+    knames = {"count_ms": ["count_kernel"], "scan_ms": ["scan_tiles_kernel", "reduce_tiles_kernel"],
+              "stats_ms": ["intron_stats_kernel<256", "intron_stats_kernel<64"]}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_summary.json")))
-        kname = {"count_ms": "count_kernel", "scan_ms": "scan_tiles_kernel", "stats_ms": "intron_stats_kernel"}[dom]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")))
         if world == 1 and args.genome == "grch38" and args.pairs == 50_000_000 and not args.stranded and args.order == "sorted":
-            traffic = pmc["kernels"][kname]["hbm_bytes_corrected"]
+            traffic = sum(pmc["kernels"][k]["hbm_bytes_corrected"] for k in knames[dom])
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "scan_tiles_kernel", "stats_ms": "intron_stats_kernel"}[dom],
