@@ -75,7 +75,9 @@ typedef struct irf_params {
     /* ---- engine sizing (no upstream counterpart) ---- */
     uint64_t junc_event_capacity;   /* device junction-event buffer, in events, before compaction  */
     uint32_t keep_depth;            /* 1: keep whole-chromosome depth after finalize (FragmentsMap)*/
-    uint32_t reserved;
+    /* ---- reader (no upstream counterpart: SURVEY App. D-1) ---- */
+    uint32_t mate_join;             /* 0: upstream's pairing, the NEXT record is the mate (name-collated input);
+                                       1: coordinate-sorted input, mates are joined by read name            */
 } irf_params;
 
 void irf_params_default(irf_params* p);

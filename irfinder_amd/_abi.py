@@ -46,7 +46,7 @@ class IrfParams(C.Structure):
         ("warn_nonuniform_abs", C.c_double),
         ("junc_event_capacity", C.c_uint64),
         ("keep_depth", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("mate_join", C.c_uint32),
     ]
 
 

@@ -182,23 +182,46 @@ void BamReader::on_record(const uint8_t* p, uint32_t block_size, bool& bad) {
     if (l_seq > 0) stats.n_nucleotides += (uint64_t)l_seq;
 
     const int32_t n_ref = (int32_t)chr_names.size();
-    if (have_pending_) {
-        have_pending_ = false;
-        const Rec& a = pending_;
-        const Rec& b = r;
-        if ((a.flag | b.flag) & P.skip_flag_mask) { stats.n_skipped += 2; return; }
-        if (a.ref_id != b.ref_id || a.ref_id < 0 || a.ref_id >= n_ref || a.pos < 0 || b.pos < 0) { stats.n_error += 2; return; }
-        if (a.pos <= b.pos) emit_pair(a, b); else emit_pair(b, a);
-        return;
-    }
-    if (r.flag & 0x1) {           // paired: the NEXT record is taken as the mate
-        std::swap(pending_, cur_);
-        have_pending_ = true;
-        return;
+    if (P.mate_join) {
+        if (r.flag & 0x1) { on_paired_by_name(p + 32, l_read_name); return; }
+    } else {
+        if (have_pending_) {
+            have_pending_ = false;
+            pair_or_drop(pending_, r);
+            return;
+        }
+        if (r.flag & 0x1) {           // paired: the NEXT record is taken as the mate
+            std::swap(pending_, cur_);
+            have_pending_ = true;
+            return;
+        }
     }
     if (r.flag & P.skip_flag_mask) { stats.n_skipped++; return; }
     if (r.ref_id < 0 || r.ref_id >= n_ref || r.pos < 0) { stats.n_error++; return; }
     emit_single(r);
+}
+
+// the two records of a pair, in arrival order: upstream's checks, then processPair on (left, right)
+void BamReader::pair_or_drop(const Rec& a, const Rec& b) {
+    const int32_t n_ref = (int32_t)chr_names.size();
+    if ((a.flag | b.flag) & P.skip_flag_mask) { stats.n_skipped += 2; return; }
+    if (a.ref_id != b.ref_id || a.ref_id < 0 || a.ref_id >= n_ref || a.pos < 0 || b.pos < 0) { stats.n_error += 2; return; }
+    if (a.pos <= b.pos) emit_pair(a, b); else emit_pair(b, a);
+}
+
+// params.mate_join (upstream pairs ADJACENT records and therefore needs name-collated input; north_star
+// feeds coordinate-sorted records).  A paired record waits under its read name until the record of the other mate
+// (flag 0x40 / 0x80) arrives; the pair then goes through exactly the checks and the assembly of the adjacent case, in
+// arrival order, so a sorted file yields the same multiset of fragments as its collated form.  A second record of the
+// SAME mate under a name (secondary / supplementary lines) displaces the waiting one, which is counted as an error
+// read, as is every record still waiting at the end of input.
+void BamReader::on_paired_by_name(const uint8_t* name, uint32_t l_read_name) {
+    std::string key((const char*)name, l_read_name ? l_read_name - 1 : 0);
+    auto it = waiting_.find(key);
+    if (it == waiting_.end()) { waiting_.emplace(std::move(key), cur_); return; }
+    if (((it->second.flag ^ cur_.flag) & 0xc0) == 0) { stats.n_error++; it->second = cur_; return; }
+    pair_or_drop(it->second, cur_);
+    waiting_.erase(it);
 }
 
 int BamReader::finish() {
@@ -207,6 +230,8 @@ int BamReader::finish() {
     if (!header_done_) { error = "BAM: truncated header"; return IRF_E_PARSE; }
     if (roff_ != raw_.size()) { error = "BAM: truncated record at end of input"; return IRF_E_PARSE; }
     if (have_pending_) { have_pending_ = false; stats.n_error++; }
+    stats.n_error += waiting_.size();
+    waiting_.clear();
     return 0;
 }
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/irf.h"
@@ -44,6 +45,8 @@ private:
     int parse_raw();
     int parse_header(bool& need_more);
     void on_record(const uint8_t* p, uint32_t block_size, bool& bad);
+    void on_paired_by_name(const uint8_t* name, uint32_t l_read_name);
+    void pair_or_drop(const Rec& a, const Rec& b);
     void emit_single(const Rec& r);
     void emit_pair(const Rec& a, const Rec& b);
 
@@ -55,6 +58,8 @@ private:
     bool header_done_ = false;
     bool have_pending_ = false;
     Rec pending_, cur_;
+    // params.mate_join: records whose mate has not been seen yet, by read name (coordinate-sorted input)
+    std::unordered_map<std::string, Rec> waiting_;
     std::vector<BlockSpan> b1_, b2_, merged_;
     void* zs_ = nullptr;
 };

@@ -262,6 +262,12 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
         (tmp_path / n).write_text(t)
     (tmp_path / "in.bam.raw").write_bytes(bam)
     (tmp_path / "in.bam").write_bytes(bgzf_compress(bam))
+    # the same records coordinate-sorted (north_star's input order): read with --sorted (mates joined by name)
+    import struct
+    from test_host_reader import _split_bam
+    head, recs = _split_bam(bam)
+    recs.sort(key=lambda r: struct.unpack_from("<ii", r, 4))
+    (tmp_path / "sorted.bam").write_bytes(bgzf_compress(head + b"".join(recs)))
     refs = [str(tmp_path / n) for n in names]
     cpu = tmp_path / "cpu"
     cpu.mkdir()
@@ -270,7 +276,8 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     assert p.returncode == 0, p.stderr
     cpu_stdout = p.stdout
     exe = os.path.join(root, "irfinder_amd", "irfinder_hip")
-    for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam")):
+    for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam"),
+                            ("sorted", ["--bgzf", "--sorted"], "sorted.bam")):
         out = tmp_path / tag
         out.mkdir()
         with open(tmp_path / src, "rb") as fh:

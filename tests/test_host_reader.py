@@ -138,3 +138,69 @@ def test_oq_switches_reach_the_reader():
         r.feed(bam)
         r.finish()
         assert r.take_batch().equals(ob) and r.stats() == ost, over
+
+
+def _split_bam(bam):
+    """raw BAM bytes -> (header bytes, [record bytes])."""
+    import struct
+    l_text, = struct.unpack_from("<i", bam, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", bam, o)
+    o += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", bam, o)
+        o += 4 + l_name + 4
+    head, recs = bam[:o], []
+    while o < len(bam):
+        bs, = struct.unpack_from("<i", bam, o)
+        recs.append(bam[o:o + 4 + bs])
+        o += 4 + bs
+    return head, recs
+
+
+def _fragment_multiset(b):
+    out = []
+    for i in range(b.n_frag):
+        a, z = int(b.frag_blk_off[i]), int(b.frag_blk_off[i + 1])
+        out.append((int(b.frag_chr[i]), int(b.frag_flags[i]), int(b.frag_start[i]), int(b.frag_end[i]),
+                    tuple(zip(b.blk_start[a:z].tolist(), b.blk_len[a:z].tolist(), b.blk_read[a:z].tolist()))))
+    return sorted(out)
+
+
+def test_mate_join_on_coordinate_sorted_input():
+    """params.mate_join: a coordinate-sorted file read with the name join gives the same multiset of
+    fragments and the same reader counters as its name-collated form read the upstream way (adjacent records)."""
+    import struct
+    ann, sim = small_world(n_pairs=0, seed=17, single_frac=0.05)
+    bam = sim.bam(0, 8000)
+    head, recs = _split_bam(bam)
+    # a few irregular records: an orphan whose mate is missing, a pair on two chromosomes, a pair with an unmapped mate
+    extra = records_to_bam(ann.chr_names, ann.chr_lens, [
+        dict(ref_id=0, pos=5000, flag=0x41, cigar="50M", name="orphan"),
+        dict(ref_id=0, pos=6000, flag=0x41, cigar="50M", name="split"), dict(ref_id=1, pos=6000, flag=0x81, cigar="50M", name="split"),
+        dict(ref_id=0, pos=7000, flag=0x41, cigar="50M", name="half"), dict(ref_id=0, pos=7000, flag=0x81 | 0x4, cigar="50M", name="half")])
+    recs_x = _split_bam(extra)[1]
+    collated = head + b"".join(recs + recs_x[1:])            # the orphan last: an unpaired trailing record
+    r0 = engine.Reader()
+    r0.feed(collated + recs_x[0])
+    r0.finish()
+    want, want_stats = _fragment_multiset(r0.take_batch()), r0.stats()
+    assert want_stats["n_error"] == 3 and want_stats["n_skipped"] == 2 and want_stats["n_pairs"] > 7000
+
+    def key(rec):
+        ref_id, pos = struct.unpack_from("<ii", rec, 4)
+        return (ref_id if ref_id >= 0 else 1 << 30, pos)
+    srt = sorted(recs + recs_x, key=key)
+    assert srt != recs + recs_x
+    r1 = engine.Reader(engine.default_params(mate_join=1))
+    data = head + b"".join(srt)
+    for i in range(0, len(data), 100003):            # odd chunking
+        r1.feed(data[i:i + 100003])
+    r1.finish()
+    assert _fragment_multiset(r1.take_batch()) == want
+    assert r1.stats() == want_stats
+    # read the upstream way, the sorted file is mis-paired (that is D-1)
+    r2 = engine.Reader()
+    r2.feed(data)
+    r2.finish()
+    assert _fragment_multiset(r2.take_batch()) != want
