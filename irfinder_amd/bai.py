@@ -47,7 +47,7 @@ class Bai:
                 w[i] = r.n_mapped
             elif len(r.linear):
                 nz = r.linear[r.linear > 0]
-                w[i] = float((int(nz.max()) >> 16) - (int(nz.min()) >> 16)) if len(nz) else 0.0
+                w[i] = float((int(nz.max()) >> 16) - (int(nz.min()) >> 16) + 1) if len(nz) else 0.0
         return w
 
     def ref_range(self, ref_id):
