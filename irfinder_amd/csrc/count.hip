@@ -34,10 +34,20 @@
 // behind it, which serialises the round trips.
 #include "kernels.h"
 
+#include <cstdio>
+
 namespace irf {
 namespace dev {
 
 namespace {
+
+#ifdef COUNT_PROF
+// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of wave 0 per phase and workgroup
+__device__ uint32_t g_cprof[1024][8];
+#define CPROF(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
+#else
+#define CPROF(k) do { } while (0)
+#endif
 
 #ifndef K_THREADS
 #define K_THREADS 256
@@ -58,7 +68,7 @@ namespace {
 #define K_WGS_PER_CU 3
 #endif
 #ifndef K_MIN_WGS
-#define K_MIN_WGS 1
+#define K_MIN_WGS 3
 #endif
 constexpr int kThreads = K_THREADS;
 constexpr int kVec = 4;                               // consecutive fragments / blocks per lane
@@ -85,7 +95,7 @@ struct Lds {
     uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
     uint32_t jcnt[2][kJCache];
     uint2 jpos[kJCache];               // plane positions of the junction's two difference events
-    uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_gpos
+    uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_pos32
     uint32_t pcnt[2][kPCache];
     unsigned long long nq[kNovelQ];
     uint32_t chr[kChrBins];
@@ -179,6 +189,10 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
 
     const uint32_t lane = tid & 63u;
     uint32_t err = 0;
+#ifdef COUNT_PROF
+    unsigned long long prof_t = wall_clock64();
+    uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
     const uint4* __restrict__ chr4 = reinterpret_cast<const uint4*>(B.frag_chr);
     const uint4* __restrict__ fs4 = reinterpret_cast<const uint4*>(B.frag_start);
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             }
         }
         __syncthreads();
+        CPROF(0);
 
         // ---------------- 2. block-parallel: 4 consecutive blocks per lane ----------------
         const uint32_t kb0 = S.off[0], kb1 = S.off[kChunk];
@@ -301,25 +316,27 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         const bool fold_ok = T.plane_stride <= 0xffffffffull;       // the junction cache keeps plane positions as uint32
         uint32_t wmax = 0;
         const uint32_t g_lastb = B.n_blk ? (B.n_blk - 1u) >> 2 : 0u;
+        // The block columns of an iteration are loaded one iteration ahead (the loads of the first iteration are issued
+        // here, before anything waits): a round trip less on the chain columns -> bucket entries -> key / point tables.
+        // Every lane also loads the block after its four itself (the junction to the right of its last block).
+        struct BlkCols { uint4 vbs, vbl; uint32_t vrd, nbs, nbl, nrd; };
+        auto load_cols = [&](uint32_t k0) -> BlkCols {
+            BlkCols c;
+            const uint32_t g = (k0 >> 2) < g_lastb ? (k0 >> 2) : g_lastb;
+            const uint32_t kn = k0 + kVec < B.n_blk ? k0 + kVec : (B.n_blk ? B.n_blk - 1u : 0u);
+            c.vbs = bs4[g]; c.vbl = bl4[g]; c.vrd = rd4[g];
+            c.nbs = B.blk_start[kn]; c.nbl = B.blk_len[kn]; c.nrd = B.blk_read[kn];
+            return c;
+        };
+        BlkCols nxt = load_cols((kb0 & ~3u) + tid * kVec);
         for (uint32_t ka = kb0 & ~3u; ka < kb1 && !(T.ablate & 32u); ka += kThreads * kVec) {
             const uint32_t k0 = ka + tid * kVec;
+            const BlkCols cur = nxt;
+            nxt = load_cols(k0 + kThreads * kVec);
             uint32_t bs[kVec + 1], bl[kVec + 1], rd[kVec + 1];
-            {
-                const uint32_t g = (k0 >> 2) < g_lastb ? (k0 >> 2) : g_lastb;
-                const uint4 vbs = bs4[g], vbl = bl4[g];
-                const uint32_t vrd = rd4[g];
-                // the block after the lane's four: the next lane's first; for the last lane, one more (wave-uniform) load
-                const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane((int)k0, 63) + kVec;
-                const uint32_t kxc = kx < B.n_blk ? kx : (B.n_blk ? B.n_blk - 1u : 0u);
-                const uint32_t xbs = B.blk_start[kxc], xbl = B.blk_len[kxc], xrd = B.blk_read[kxc];
-                bs[0] = vbs.x; bs[1] = vbs.y; bs[2] = vbs.z; bs[3] = vbs.w;
-                bl[0] = vbl.x; bl[1] = vbl.y; bl[2] = vbl.z; bl[3] = vbl.w;
-                rd[0] = vrd & 0xffu; rd[1] = (vrd >> 8) & 0xffu; rd[2] = (vrd >> 16) & 0xffu; rd[3] = vrd >> 24;
-                const uint32_t nbs = __shfl_down(bs[0], 1), nbl = __shfl_down(bl[0], 1), nrd = __shfl_down(rd[0], 1);
-                bs[4] = lane == 63u ? xbs : nbs;
-                bl[4] = lane == 63u ? xbl : nbl;
-                rd[4] = lane == 63u ? xrd : nrd;
-            }
+            bs[0] = cur.vbs.x; bs[1] = cur.vbs.y; bs[2] = cur.vbs.z; bs[3] = cur.vbs.w; bs[4] = cur.nbs;
+            bl[0] = cur.vbl.x; bl[1] = cur.vbl.y; bl[2] = cur.vbl.z; bl[3] = cur.vbl.w; bl[4] = cur.nbl;
+            rd[0] = cur.vrd & 0xffu; rd[1] = (cur.vrd >> 8) & 0xffu; rd[2] = (cur.vrd >> 16) & 0xffu; rd[3] = cur.vrd >> 24; rd[4] = cur.nrd;
             // owner = the last fragment of the chunk whose offset is <= k (empty fragments share an offset with
             // their successor and are never picked): binary search for the first block, a short walk for the others
             uint32_t fbv[kVec], clen[kVec];
@@ -372,6 +389,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             }
 #pragma unroll
             for (int j = 0; j < kVec; j++) ee[j] = T.bkt[ok[j] ? gbe[j] >> kBucketShift : 0ull];
+            CPROF(1);
             // junction to the right of the block: both flanks long enough, same read, same fragment
             bool jc[kVec];
             uint64_t jkey[kVec], kfirst[kVec];
@@ -386,6 +404,23 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                 const bool kq = jc[j] && (ee[j].w >> 16);
                 kfirst[j] = T.known_keys[kq ? ee[j].z : 0u];                  // the table holds at least one entry
                 if (!kq) kfirst[j] = ~0ull;
+            }
+            // SpansPoint: the first four points under every block are requested now, together with the junction keys
+            // (one round trip for all four blocks of the lane; points are compared modulo 2^32)
+            uint32_t sp_p[kVec], sp_p1[kVec], sp_g[kVec][4];
+            {
+                const uint32_t sp_last = T.n_sp_dev ? T.n_sp_dev - 1u : 0u;
+#pragma unroll
+                for (int j = 0; j < kVec; j++) {
+                    const bool on = ok[j] && bl[j] > T.sp_min_len && !(T.ablate & 2u);
+                    sp_p[j] = es[j].y;
+                    sp_p1[j] = on ? ee[j].y + (ee[j].w & 0xffffu) : sp_p[j];      // saturated count: a lower bound, fixed below
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t i = sp_p[j] + q < sp_last ? sp_p[j] + q : sp_last;
+                        sp_g[j][q] = T.sp_pos32[i];
+                    }
+                }
             }
             // known junction?  (index into known_keys, or kEmpty)
             uint32_t hit[kVec];
@@ -411,6 +446,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                     }
                 }
             }
+            CPROF(2);
             // JunctionCount on known junctions: the junction's LDS counter (same-address LDS atomics of a wave are
             // serialised by the hardware at about a lane per clock: cheaper than electing leaders in software).
             // folded = the junction's counter now also stands for this read's two difference events
@@ -423,6 +459,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                                              plane_of(T, es[j + 1].x, gbs[j + 1])) && fold_ok;
                 }
             }
+            CPROF(3);
             // difference events, SpansPoint, novel junctions
 #pragma unroll
             for (int j = 0; j < kVec; j++) {
@@ -437,34 +474,42 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                         if (next_same[j] && ok[j + 1]) depth_event(T, S, win, use_win, plane_of(T, es[j + 1].x, gbs[j + 1]), dir, 1, wmax);
                     }
                 }
-                // SpansPoint: the points of the buckets under the block, filtered to [lo, hi]; four points per round
-                // trip (the first ones usually are the block's own exon boundaries, just outside [lo, hi])
-                if (bl[j] > T.sp_min_len && !(T.ablate & 2u)) {
-                    uint32_t p = es[j].y;
+                // SpansPoint: the points of the buckets under the block, filtered to [lo, hi].  The first four were
+                // requested above (they usually are the block's own exon boundaries, just outside [lo, hi], and the
+                // few points inside); more only for a block over a dense stretch
+                if (sp_p[j] < sp_p1[j]) {
+                    uint32_t p = sp_p[j];
                     const uint32_t pn = ee[j].w & 0xffffu;
-                    const uint32_t p1 = pn == 0xffffu ? T.bkt[(gbe[j] >> kBucketShift) + 1u].y : ee[j].y + pn;
-                    const uint64_t lo = gbs[j] + T.sp_lo_add, hi = gbe[j] - T.sp_hi_sub;
+                    const uint32_t p1 = pn == 0xffffu ? T.bkt[(gbe[j] >> kBucketShift) + 1u].y : sp_p1[j];
+                    const uint32_t lo = (uint32_t)gbs[j] + T.sp_lo_add, hi = (uint32_t)gbe[j] - T.sp_hi_sub;
                     uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
-                    while (p < p1) {
-                        uint64_t gp[4];
+                    auto point = [&](uint32_t pi) {
+                        const uint32_t slot = pi & (kPCache - 1u);
+                        uint32_t tag = S.ptag[slot];
+                        if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ptag[slot], kEmpty, pi); tag = old == kEmpty ? pi : old; }
+                        if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
+                        else atomicAdd(&sp_cnt[T.sp_row[pi]], 1u);
+                    };
+                    bool done = false;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) gp[q] = T.sp_gpos[p + q < p1 ? p + q : p1 - 1u];
-                        bool done = false;
+                    for (int q = 0; q < 4; q++) {
+                        if (p + q < p1 && !done) {
+                            const uint32_t g = sp_g[j][q];
+                            if ((int32_t)(g - hi) > 0) done = true;
+                            else if ((int32_t)(g - lo) >= 0) point(p + q);
+                        }
+                    }
+                    for (p += 4u; !done && p < p1; p += 4u) {
+                        uint32_t gp[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) gp[q] = T.sp_pos32[p + q < p1 ? p + q : p1 - 1u];
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             if (p + q < p1 && !done) {
-                                if (gp[q] > hi) done = true;
-                                else if (gp[q] >= lo) {
-                                    const uint32_t pi = p + q, slot = pi & (kPCache - 1u);
-                                    uint32_t tag = S.ptag[slot];
-                                    if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ptag[slot], kEmpty, pi); tag = old == kEmpty ? pi : old; }
-                                    if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
-                                    else atomicAdd(&sp_cnt[T.sp_row[pi]], 1u);
-                                }
+                                if ((int32_t)(gp[q] - hi) > 0) done = true;
+                                else if ((int32_t)(gp[q] - lo) >= 0) point(p + q);
                             }
                         }
-                        if (done) break;
-                        p += 4u;
                     }
                 }
                 if (jc[j] && hit[j] == kEmpty) {
@@ -485,8 +530,10 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                     }
                 }
             }
+            CPROF(7);
         }
         __syncthreads();
+        CPROF(4);
 
         // ---------------- 3. flush the LDS accumulators ----------------
         // 3a. the junction cache: counters to the table, the junctions' difference events into window / line cache
@@ -519,6 +566,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         }
         if (wmax) atomicMax(&S.wmax, wmax);
         __syncthreads();
+        CPROF(5);
         // 3b. line cache and window: consecutive lanes = consecutive positions, so that a wave's atomics fall into
         //     whole 64-byte lines (the memory-side atomic unit works per line)
         const uint32_t wtop = S.wmax;
@@ -554,6 +602,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             }
         }
         __syncthreads();
+        CPROF(6);
         for (uint32_t e = tid; e < kLines; e += kThreads) S.ltag[e] = kEmpty;
         if (tid == 0) { S.nq_n = 0; S.wmax = 0; }
         if (nq) {
@@ -563,6 +612,9 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             }
         }
     }
+#ifdef COUNT_PROF
+    if (tid == 0 && blockIdx.x < 1024u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][k] = prof_acc[k];
+#endif
     if (err) atomicOr(T.err_flags, err);
     __syncthreads();
     for (int k = tid; k < kChrBins; k += kThreads) {
@@ -579,6 +631,18 @@ void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
     uint32_t blocks = ((n_chunks + 7u) / 8u) * 8u;            // a multiple of 8 for the XCD mapping
     if (blocks > 256u * K_WGS_PER_CU) blocks = 256u * K_WGS_PER_CU;
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, T, B);
+#ifdef COUNT_PROF
+    {
+        static uint32_t h[1024][8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cprof), sizeof h);
+        double a[8] = {0};
+        for (uint32_t w = 0; w < blocks && w < 1024u; w++) for (int k = 0; k < 8; k++) a[k] += h[w][k];
+        fprintf(stderr, "count_prof ticks/wg: fragment phase %.0f | block loop: columns+owner+bucket requests %.0f, junction keys + SpansPoint requests + key search %.0f, "
+                        "junction counters %.0f, events+points+novel %.0f | barrier %.0f | flush junction/point caches %.0f, flush lines+window %.0f\n",
+                a[0] / blocks, a[1] / blocks, a[2] / blocks, a[3] / blocks, a[7] / blocks, a[4] / blocks, a[5] / blocks, a[6] / blocks);
+    }
+#endif
 }
 
 }   // namespace dev

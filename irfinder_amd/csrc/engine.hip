@@ -101,9 +101,10 @@ struct irf_ctx {
     DevBuf<uint32_t> d_roi_idx, d_roi_bucket, d_roi_cnt;
     DevBuf<uint64_t> d_roi_gstart, d_roi_gend;
     uint32_t n_roi_dev = 0;
+    size_t n_sp_dev = 0;                         // SpansPoint entries on owned chromosomes (device tables)
     DevBuf<uint32_t> d_sp_row, d_sp_cnt;
     DevBuf<uint4> d_bkt;                         // kernels.h: CountTables::bkt
-    DevBuf<uint64_t> d_sp_gpos;
+    DevBuf<uint32_t> d_sp_pos32;                 // SpansPoint: low 32 bits of the points' full coordinates, sorted
     DevBuf<uint64_t> d_junc_a, d_junc_b;
     DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
     DevBuf<uint32_t> d_err;
@@ -361,7 +362,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     // ---- SpansPoint: (slot,pos)-sorted; reference-only chromosomes at the tail ----
     n_sp = (uint32_t)ref.sp_pos.size();
     std::vector<uint32_t> sp_bucket_h;
-    size_t n_sp_dev = 0;
+    n_sp_dev = 0;
     {
         std::vector<uint64_t> key(n_sp);
         for (uint32_t i = 0; i < n_sp; i++) key[i] = ((uint64_t)refchr_slot[ref.sp_chr[i]] << 32) | ref.sp_pos[i];
@@ -387,7 +388,11 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             }
         }
         n_sp_dev = gpos.size();
-        TRY(upload(this, d_sp_gpos, gpos));
+        {   // the count kernel compares points with block ends modulo 2^32 (all within one block span of each other)
+            std::vector<uint32_t> lo32(gpos.size());
+            for (size_t i = 0; i < gpos.size(); i++) lo32[i] = (uint32_t)gpos[i];
+            TRY(upload(this, d_sp_pos32, lo32));
+        }
         TRY(upload(this, d_sp_row, row));
         sp_bucket_h.swap(bucket);
         TRY(alloc_zero(this, d_sp_cnt, (size_t)n_sp * 2));
@@ -614,7 +619,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p; T.roi_bucket = d_roi_bucket.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
-    T.sp_gpos = d_sp_gpos.p; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
+    T.sp_pos32 = d_sp_pos32.p; T.n_sp_dev = (uint32_t)n_sp_dev; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
     T.known_keys = d_known_keys.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
     T.junc_keys = d_junc_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
     return T;

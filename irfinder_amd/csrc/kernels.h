@@ -68,10 +68,11 @@ struct CountTables {
     const uint32_t* roi_idx;    // file index of the sorted ROI
     const uint32_t* roi_bucket; // [(full_size >> kBucketShift) + 2] first ROI with gend >= b << kBucketShift
     uint32_t n_roi_dev;
-    uint32_t pad2;
+    uint32_t n_sp_dev;         // entries of sp_pos32 / sp_row
     uint32_t* roi_cnt;         // [2][n_roi]
     // SpansPoint: points on owned chromosomes in full coordinates (range per bucket: bkt)
-    const uint64_t* sp_gpos;   // [n_sp_own] sorted
+    const uint32_t* sp_pos32;  // [n_sp_dev] the points' full coordinates, sorted, low 32 bits (compared modulo 2^32 with
+                               // block ends at most one block span + two buckets away)
     const uint32_t* sp_row;    // [n_sp_own] row in sp_cnt
     uint32_t* sp_cnt;          // [2][n_sp]
     // known junctions (ref-sj.ref) on owned chromosomes: events that hit one are counted in place,
