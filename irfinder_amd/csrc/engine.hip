@@ -585,8 +585,9 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
 
 int irf_ctx::zero_counters() {
     HIP_TRY(hipSetDevice(device));
-    // (clearing a second set of planes on a side stream under the next sample's count kernel was tried: the count
-    //  kernel slows down by exactly the time of the memset, so the planes are cleared in line)
+    // (clearing a second set of planes on a side stream was tried twice: under the next sample's count kernel that kernel
+    //  slows down by exactly the time of the memset, under the statistics kernels they slow down by MORE than that
+    //  (1.85 -> 3.13 ms) — both are latency-bound and lose to a bandwidth-bound neighbour; the planes are cleared in line)
     if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
     if (plane_stride) HIP_TRY(hipMemsetAsync(d_seg_sum.p, 0, 2 * plane_stride / dev::kDepthSegment * sizeof(uint32_t), stream));
     if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
