@@ -237,7 +237,8 @@ def main():
         # scans them (read + write of 4 B per segment and strand); the planes are not read again, depth is never written
         "scan_ms": (G // 256) * 2 * 4 * 2,
         # statistics: 4 B per measured intron base and strand (both strands for the non-directional table)
-        "stats_ms": lay["measured_positions"] * 2 * 4,
+        # (+ one strand once more when the directional table is computed as well)
+        "stats_ms": lay["measured_positions"] * 2 * 4 + (lay["measured_positions"] * 4 if "ir_dir_f64" in out["got"] else 0),
     }
     dom = max(alg, key=lambda k: kt[k])
     achieved = alg[dom] / (kt[dom] * 1e-3) / 1e9 if kt[dom] > 0 else 0.0
