@@ -300,6 +300,10 @@ void irf_reader_destroy(irf_reader* r);
 const char* irf_reader_last_error(const irf_reader* r);
 /* Feed bytes (any chunking).  is_bgzf: 1 = BGZF-compressed, 0 = raw BAM.     */
 int irf_reader_feed(irf_reader* r, const uint8_t* data, size_t len, int is_bgzf);
+/* BGZF members of one irf_reader_feed call are inflated and CRC-checked by n_threads threads (1..64; default 1).
+ * No upstream counterpart: ⟨upstream⟩ bin/IRFinder pipes `gzip -cd` (one thread) into the engine.  The record
+ * parser stays sequential (mate pairing is), so feed in large pieces (MiB) for the threads to have work.        */
+int irf_reader_set_threads(irf_reader* r, int n_threads);
 /* Header (valid once parsed): returns n_ref, or a negative status if the
  * header is not complete yet.                                                */
 int irf_reader_header(const irf_reader* r, const char* const** names, const uint32_t** lens);

@@ -89,6 +89,7 @@ def lib():
     L.irf_reader_last_error.argtypes = [vp]
     L.irf_reader_last_error.restype = C.c_char_p
     L.irf_reader_feed.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_int]
+    L.irf_reader_set_threads.argtypes = [vp, C.c_int]
     L.irf_reader_header.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(u32))]
     L.irf_reader_batch.argtypes = [vp, C.POINTER(IrfBatch)]
     L.irf_reader_clear_batch.argtypes = [vp]
@@ -169,13 +170,15 @@ class RefTables:
 class Reader:
     """Host BAM reader (BAM2blocks replacement): bytes in, SoA fragment batches out."""
 
-    def __init__(self, params=None):
+    def __init__(self, params=None, threads=1):
         self.L = lib()
         self.params = params or default_params()
         self.h = C.c_void_p()
         rc = self.L.irf_reader_create(C.byref(self.params), C.byref(self.h))
         if rc != 0:
             raise IrfError(rc, "irf_reader_create")
+        if threads != 1:
+            self._chk(self.L.irf_reader_set_threads(self.h, int(threads)))
 
     def _chk(self, rc):
         if rc != 0:

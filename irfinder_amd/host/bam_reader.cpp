@@ -34,18 +34,83 @@ uint32_t cigar_to_blocks(uint32_t pos, const uint32_t* cigar, uint32_t n_cigar, 
     return origin + run;
 }
 
-BamReader::BamReader(const irf_params& p) : P(p) {
-    memset(&stats, 0, sizeof stats);
+WorkerPool::WorkerPool(int n_threads) {
+    for (int i = 1; i < n_threads; i++) threads_.emplace_back(&WorkerPool::worker_main, this, i);
+}
+
+WorkerPool::~WorkerPool() {
+    {
+        std::lock_guard<std::mutex> g(m_);
+        stop_ = true;
+    }
+    wake_.notify_all();
+    for (auto& t : threads_) t.join();
+}
+
+void WorkerPool::drain(int id) {
+    for (size_t i = next_.fetch_add(1); i < n_items_; i = next_.fetch_add(1)) (*fn_)(id, i);
+}
+
+void WorkerPool::worker_main(int id) {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    while (true) {
+        wake_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+        lk.unlock();
+        drain(id);
+        lk.lock();
+        if (--busy_ == 0) done_.notify_one();
+    }
+}
+
+void WorkerPool::start(size_t first, size_t end, const std::function<void(int, size_t)>& fn) {
+    {
+        std::lock_guard<std::mutex> g(m_);
+        fn_ = &fn;
+        n_items_ = end;
+        next_.store(first);
+        busy_ = (int)threads_.size();
+        generation_++;
+    }
+    wake_.notify_all();
+}
+
+void WorkerPool::wait() {
+    drain(0);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return busy_ == 0; });
+    fn_ = nullptr;
+}
+
+static void* new_zstream() {
     z_stream* zs = new z_stream();
     memset(zs, 0, sizeof *zs);
     inflateInit2(zs, -15);
-    zs_ = zs;
+    return zs;
+}
+
+BamReader::BamReader(const irf_params& p) : P(p) {
+    memset(&stats, 0, sizeof stats);
+    zs_.push_back(new_zstream());
 }
 
 BamReader::~BamReader() {
-    z_stream* zs = (z_stream*)zs_;
-    inflateEnd(zs);
-    delete zs;
+    delete pool_;
+    for (void* z : zs_) {
+        inflateEnd((z_stream*)z);
+        delete (z_stream*)z;
+    }
+}
+
+void BamReader::set_threads(int n) {
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    if (pool_ && pool_->size() == n) return;
+    delete pool_;
+    pool_ = n > 1 ? new WorkerPool(n) : nullptr;
+    while ((int)zs_.size() < n) zs_.push_back(new_zstream());
 }
 
 int BamReader::feed(const uint8_t* data, size_t len, bool bgzf) {
@@ -59,17 +124,21 @@ int BamReader::feed(const uint8_t* data, size_t len, bool bgzf) {
         if (roff_ > 0 && roff_ == raw_.size()) { raw_.clear(); roff_ = 0; }
         raw_.insert(raw_.end(), data, data + len);
     }
-    return parse_raw();
+    return parse_raw(raw_.size(), true);
 }
 
-// BGZF (SAM spec §4.1): gzip members with a 'BC' extra subfield carrying BSIZE.
+// BGZF (SAM spec §4.1): gzip members with a 'BC' extra subfield carrying BSIZE.  The complete members in the buffer are
+// located first (their inflated sizes are in the trailers, so every member knows where its output goes), then
+// inflated and CRC-checked independently — by the worker pool when there is one.
 int BamReader::inflate_blocks() {
-    z_stream* zs = (z_stream*)zs_;
+    zblocks_.clear();
+    size_t scan = zoff_, total_out = 0;
+    std::string scan_error;
     while (true) {
-        size_t avail = zbuf_.size() - zoff_;
+        size_t avail = zbuf_.size() - scan;
         if (avail < 18) break;
-        const uint8_t* h = zbuf_.data() + zoff_;
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { error = "BGZF: bad member header"; return IRF_E_PARSE; }
+        const uint8_t* h = zbuf_.data() + scan;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { scan_error = "BGZF: bad member header"; break; }
         uint32_t xlen = le16(h + 10);
         if (avail < 12 + (size_t)xlen) break;
         uint32_t bsize = 0;
@@ -80,37 +149,83 @@ int BamReader::inflate_blocks() {
             if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = le16(sf + 4); found = true; }
             x += 4 + slen;
         }
-        if (!found) { error = "BGZF: missing BC subfield"; return IRF_E_PARSE; }
+        if (!found) { scan_error = "BGZF: missing BC subfield"; break; }
         size_t total = (size_t)bsize + 1;
-        if (total < 12 + (size_t)xlen + 8) { error = "BGZF: bad BSIZE"; return IRF_E_PARSE; }
+        if (total < 12 + (size_t)xlen + 8) { scan_error = "BGZF: bad BSIZE"; break; }
         if (avail < total) break;
-        size_t clen = total - 12 - xlen - 8;
-        uint32_t crc = le32(h + total - 8), isize = le32(h + total - 4);
-        if (isize > 65536) { error = "BGZF: ISIZE > 64 KiB"; return IRF_E_PARSE; }
-        if (isize) {
-            if (roff_ > (1u << 20) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
-            size_t at = raw_.size();
-            raw_.resize(at + isize);
-            inflateReset(zs);
-            zs->next_in = const_cast<Bytef*>(h + 12 + xlen);
-            zs->avail_in = (uInt)clen;
-            zs->next_out = raw_.data() + at;
-            zs->avail_out = isize;
-            int zr = inflate(zs, Z_FINISH);
-            if (zr != Z_STREAM_END || zs->avail_out != 0) { raw_.resize(at); error = "BGZF: inflate failed"; return IRF_E_PARSE; }
-            if ((uint32_t)crc32(0L, raw_.data() + at, isize) != crc) { raw_.resize(at); error = "BGZF: CRC mismatch"; return IRF_E_PARSE; }
-        }
-        zoff_ += total;
+        ZBlock b;
+        b.in_off = scan + 12 + xlen;
+        b.clen = total - 12 - xlen - 8;
+        b.crc = le32(h + total - 8);
+        b.isize = le32(h + total - 4);
+        if (b.isize > 65536) { scan_error = "BGZF: ISIZE > 64 KiB"; break; }
+        b.out_off = total_out;
+        total_out += b.isize;
+        zblocks_.push_back(b);
+        scan += total;
     }
+    // (the members before a malformed one are still inflated, as when reading them one by one; the error is sticky)
+    if (roff_ > (1u << 20) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
+    const size_t at = raw_.size();
+    raw_.resize(at + total_out);
+    std::atomic<size_t> first_bad(zblocks_.size());
+    std::vector<int> why(zblocks_.size(), 0);
+    const uint8_t* in = zbuf_.data();
+    uint8_t* out = raw_.data() + at;
+    // (a std::function object of its own: the pool keeps a pointer to it between start() and wait())
+    const std::function<void(int, size_t)> one = [&](int worker, size_t i) {
+        const ZBlock& b = zblocks_[i];
+        if (!b.isize) return;
+        z_stream* zs = (z_stream*)zs_[(size_t)worker];
+        inflateReset(zs);
+        zs->next_in = const_cast<Bytef*>(in + b.in_off);
+        zs->avail_in = (uInt)b.clen;
+        zs->next_out = out + b.out_off;
+        zs->avail_out = b.isize;
+        int zr = inflate(zs, Z_FINISH);
+        int bad = 0;
+        if (zr != Z_STREAM_END || zs->avail_out != 0) bad = 1;
+        else if ((uint32_t)crc32(0L, out + b.out_off, b.isize) != b.crc) bad = 2;
+        if (bad) {
+            why[i] = bad;
+            size_t cur = first_bad.load();
+            while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+        }
+    };
+    int parse_rc = 0;
+    if (pool_ && zblocks_.size() >= 16) {
+        // four waves: while the workers inflate wave w + 1, this thread parses what wave w produced
+        const size_t n = zblocks_.size(), step = (n + 3) / 4;
+        pool_->run(step, one);
+        for (size_t w0 = step; w0 < n && parse_rc == 0; w0 += step) {
+            const size_t w1 = w0 + step < n ? w0 + step : n;
+            pool_->start(w0, w1, one);
+            if (first_bad.load() == n) parse_rc = parse_raw(at + zblocks_[w0].out_off, false);
+            pool_->wait();
+        }
+    } else if (pool_ && zblocks_.size() >= 4) {
+        pool_->run(zblocks_.size(), one);
+    } else {
+        for (size_t i = 0; i < zblocks_.size() && first_bad.load() == zblocks_.size(); i++) one(0, i);
+    }
+    if (parse_rc != 0) return parse_rc;
+    const size_t fb = first_bad.load();
+    if (fb < zblocks_.size()) {
+        raw_.resize(at + zblocks_[fb].out_off);
+        error = why[fb] == 2 ? "BGZF: CRC mismatch" : "BGZF: inflate failed";
+        return IRF_E_PARSE;
+    }
+    zoff_ = scan;
+    if (!scan_error.empty()) { error = scan_error; return IRF_E_PARSE; }
     if (zoff_ > (1u << 20) && zoff_ * 2 > zbuf_.size()) { zbuf_.erase(zbuf_.begin(), zbuf_.begin() + (ptrdiff_t)zoff_); zoff_ = 0; }
     return 0;
 }
 
 // ⟨upstream⟩ BAM2blocks::readBamHeader
-int BamReader::parse_header(bool& need_more) {
+int BamReader::parse_header(bool& need_more, size_t limit) {
     need_more = true;
     const uint8_t* p = raw_.data() + roff_;
-    size_t avail = raw_.size() - roff_, o = 0;
+    size_t avail = limit - roff_, o = 0;
     if (avail < 12) return 0;
     if (memcmp(p, "BAM\1", 4) != 0) { error = "BAM: bad magic"; return IRF_E_PARSE; }
     int32_t l_text = (int32_t)le32(p + 4);
@@ -144,15 +259,16 @@ int BamReader::parse_header(bool& need_more) {
 }
 
 // ⟨upstream⟩ BAM2blocks::processAll — record loop with adjacent-mate pairing
-int BamReader::parse_raw() {
+int BamReader::parse_raw(size_t limit, bool may_compact) {
+    // only raw_[.. limit) is final (the worker threads may still be inflating behind it; then raw_ must not move)
     if (!header_done_) {
         bool need_more;
-        int rc = parse_header(need_more);
+        int rc = parse_header(need_more, limit);
         if (rc != 0) return rc;
         if (need_more) return 0;
     }
     while (true) {
-        size_t avail = raw_.size() - roff_;
+        size_t avail = limit - roff_;
         if (avail < 4) break;
         const uint8_t* p = raw_.data() + roff_;
         uint32_t block_size = le32(p);
@@ -163,7 +279,7 @@ int BamReader::parse_raw() {
         if (bad) return IRF_E_PARSE;
         roff_ += 4 + (size_t)block_size;
     }
-    if (roff_ > (1u << 22) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
+    if (may_compact && roff_ > (1u << 22) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
     return 0;
 }
 

@@ -7,8 +7,13 @@
 // bytes) and assembles fragments straight into SoA batches for the device.
 // Fragment semantics: SURVEY App. B.1 (recalled; OQ-1/2/3 are irf_params).
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -20,6 +25,32 @@ namespace irf {
 // cigar words -> absolute aligned blocks; returns the reference end of the read
 uint32_t cigar_to_blocks(uint32_t pos, const uint32_t* cigar, uint32_t n_cigar, std::vector<BlockSpan>& out);
 
+// A few persistent worker threads that share a loop over item indices (BGZF blocks are independent deflate members:
+// SURVEY §8 f N1).  run() returns when every index has been processed; the caller's thread works too.
+class WorkerPool {
+public:
+    explicit WorkerPool(int n_threads);
+    ~WorkerPool();
+    int size() const { return (int)threads_.size() + 1; }
+    void run(size_t n_items, const std::function<void(int worker, size_t item)>& fn) { start(0, n_items, fn); wait(); }
+    // items [first, end) go to the worker threads; the caller may do other work before wait(), which helps to finish
+    void start(size_t first, size_t end, const std::function<void(int worker, size_t item)>& fn);
+    void wait();
+
+private:
+    void worker_main(int id);
+    void drain(int id);
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int, size_t)>* fn_ = nullptr;
+    size_t n_items_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t generation_ = 0;
+    int busy_ = 0;
+    bool stop_ = false;
+};
+
 class BamReader {
 public:
     explicit BamReader(const irf_params& p);
@@ -27,6 +58,8 @@ public:
     int feed(const uint8_t* data, size_t len, bool bgzf);
     int finish();
     bool header_done() const { return header_done_; }
+    // BGZF blocks of one feed() call are inflated by n threads (the record parser stays sequential: pairing is)
+    void set_threads(int n);
 
     std::vector<std::string> chr_names;
     std::vector<uint32_t> chr_lens;
@@ -42,8 +75,8 @@ private:
         std::vector<uint32_t> cigar;
     };
     int inflate_blocks();
-    int parse_raw();
-    int parse_header(bool& need_more);
+    int parse_raw(size_t limit, bool may_compact);
+    int parse_header(bool& need_more, size_t limit);
     void on_record(const uint8_t* p, uint32_t block_size, bool& bad);
     void on_paired_by_name(const uint8_t* name, uint32_t l_read_name);
     void pair_or_drop(const Rec& a, const Rec& b);
@@ -61,7 +94,10 @@ private:
     // params.mate_join: records whose mate has not been seen yet, by read name (coordinate-sorted input)
     std::unordered_map<std::string, Rec> waiting_;
     std::vector<BlockSpan> b1_, b2_, merged_;
-    void* zs_ = nullptr;
+    struct ZBlock { size_t in_off, clen, out_off; uint32_t isize, crc; };
+    std::vector<ZBlock> zblocks_;
+    std::vector<void*> zs_;              // one z_stream per worker
+    WorkerPool* pool_ = nullptr;
 };
 
 }   // namespace irf

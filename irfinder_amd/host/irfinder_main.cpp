@@ -1,13 +1,14 @@
 // irfinder_main.cpp — command-line drop-in for the upstream engine binary.
 //
 //   irfinder_hip OUTDIR ref-cover.bed ref-sj.ref ref-read-continues.ref ref-ROI.bed [--bgzf] [--device N]
-//                [--via-adapter] [--sorted] < input.bam
+//                [--via-adapter] [--sorted] [--threads N] < input.bam
 //
 // Same positional argv as ⟨upstream⟩ irfinder.cpp main(): reads the
 // BAM stream from stdin (raw, as `gzip -cd x.bam` yields it, or BGZF with
 // --bgzf), writes the IRFinder-*.txt files into OUTDIR and the reader summary
 // to stdout.  --sorted: the input is coordinate-sorted, mates are joined by read name (params.mate_join; upstream
-// needs name-collated input because it pairs adjacent records).  --via-adapter routes every fragment through the
+// needs name-collated input because it pairs adjacent records).  --threads N: BGZF members are inflated by N threads
+// (upstream's pipe has one gzip process).  --via-adapter routes every fragment through the
 // ReadBlockProcessor-shaped adapter (hip_block_processor.h) instead of handing
 // the reader's SoA batches to the engine directly; both give identical files.
 #include <cstdio>
@@ -27,16 +28,17 @@ static int die(const char* what, const char* msg) {
 int main(int argc, char** argv) {
     std::vector<const char*> pos;
     bool bgzf = false, via_adapter = false, sorted_input = false;
-    int device = 0;
+    int device = 0, threads = 1;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--bgzf")) bgzf = true;
         else if (!strcmp(argv[i], "--via-adapter")) via_adapter = true;
         else if (!strcmp(argv[i], "--sorted")) sorted_input = true;
+        else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 5) {
-        fprintf(stderr, "usage: %s OUTDIR ref-cover.bed ref-sj.ref ref-read-continues.ref ref-ROI.bed [--bgzf] [--sorted] [--device N] < bam\n", argv[0]);
+        fprintf(stderr, "usage: %s OUTDIR ref-cover.bed ref-sj.ref ref-read-continues.ref ref-ROI.bed [--bgzf] [--sorted] [--threads N] [--device N] < bam\n", argv[0]);
         return 2;
     }
     irf_params P;
@@ -44,6 +46,7 @@ int main(int argc, char** argv) {
     P.mate_join = sorted_input ? 1u : 0u;
     irf_reader* rd = nullptr;
     if (irf_reader_create(&P, &rd) != 0) return die("reader", "cannot create");
+    if (threads != 1 && irf_reader_set_threads(rd, threads) != 0) return die("--threads", "1..64");
 
     const size_t kChunk = 8u << 20, kBatchFrags = 1u << 20;
     std::vector<uint8_t> buf(kChunk);

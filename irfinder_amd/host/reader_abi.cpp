@@ -37,6 +37,12 @@ int irf_reader_feed(irf_reader* r, const uint8_t* data, size_t len, int is_bgzf)
     return r->impl.feed(data, len, is_bgzf != 0);
 }
 
+int irf_reader_set_threads(irf_reader* r, int n_threads) {
+    if (!r || n_threads < 1 || n_threads > 64) return IRF_E_ARG;
+    r->impl.set_threads(n_threads);
+    return 0;
+}
+
 int irf_reader_header(const irf_reader* r, const char* const** names, const uint32_t** lens) {
     if (!r) return IRF_E_ARG;
     if (!r->impl.header_done()) return IRF_E_STATE;

@@ -277,7 +277,7 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     cpu_stdout = p.stdout
     exe = os.path.join(root, "irfinder_amd", "irfinder_hip")
     for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam"),
-                            ("sorted", ["--bgzf", "--sorted"], "sorted.bam")):
+                            ("sorted", ["--bgzf", "--sorted", "--threads", "4"], "sorted.bam")):
         out = tmp_path / tag
         out.mkdir()
         with open(tmp_path / src, "rb") as fh:

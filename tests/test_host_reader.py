@@ -204,3 +204,34 @@ def test_mate_join_on_coordinate_sorted_input():
     r2.feed(data)
     r2.finish()
     assert _fragment_multiset(r2.take_batch()) != want
+
+
+def test_threaded_bgzf_decode_is_identical_and_reports_the_same_errors():
+    """irf_reader_set_threads: BGZF members inflated by a worker pool while the parser runs — same batch, same counters,
+    same errors as the single-threaded reader, for large and small feeds."""
+    ann, sim = small_world(n_pairs=0, seed=41, read_len=100, with_seq=True)
+    bam = sim.bam(0, 12000)
+    z = bgzf_compress(bam, block=0x2000)                      # many members per feed
+    r1 = engine.Reader()
+    r1.feed(z, bgzf=True)
+    r1.finish()
+    want, want_stats = r1.take_batch(), r1.stats()
+    for threads, piece in ((4, len(z)), (3, 300_000), (8, 4097)):
+        r = engine.Reader(threads=threads)
+        for i in range(0, len(z), piece):
+            r.feed(z[i:i + piece], bgzf=True)
+        r.finish()
+        assert r.take_batch().equals(want) and r.stats() == want_stats, (threads, piece)
+    # a corrupted member in the middle: same sticky error either way, nothing after it is parsed
+    bad = bytearray(z)
+    bad[len(z) // 2] ^= 0x55
+    msgs = []
+    for threads in (1, 4):
+        r = engine.Reader(threads=threads)
+        with pytest.raises(engine.IrfError) as ei:
+            r.feed(bytes(bad), bgzf=True)
+            r.finish()
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1] and "BGZF" in msgs[0]
+    with pytest.raises(engine.IrfError):
+        engine.Reader(threads=0)
