@@ -349,3 +349,47 @@ def test_chr22_scale_matches_oracle_and_properties():
         left_sum[int(l)] = left_sum.get(int(l), 0) + int(t)
     exp = np.array([left_sum.get(int(s), 0) for s in starts])
     assert np.array_equal(exp, g["nondir"]["splice_left"])
+
+
+def test_full_size_properties_configs1():
+    """BASELINE configs[1] at full size (50 M simulated 2x150 pairs, GRCh38-sized reference): too large to diff against
+    the oracle inside the test suite (bench.py does that once per run: `sample_rows_match_oracle`), so the
+    size-independent properties carry it —
+      P1/P2 the coordinate-sorted batch in one submit == the unsorted generator chunks in 25 submits, every table bit for bit;
+      P5    sum of FragmentsInChr == fragments; every junction event is counted once (known in place + novel sorted);
+      P6    SpliceLeft / SpliceRight of an intron == sum of the junction rows that share its start / end;
+      and an independent numpy recount of FragmentsInChr and of the reads on known junctions."""
+    from irfinder_amd.synth import world as synth_world
+    from irfinder_amd.synth.annotation import GRCH38, make_annotation
+    from irfinder_amd.synth.reads import ReadSimulator
+    ann = make_annotation(GRCH38, seed=20240808)
+    sim = ReadSimulator(ann, read_len=150, seed=20240808 + 1000)
+    batches, st = synth_world.generate_batches(sim, 0, 50_000_000, chunk=2_000_000, threads=16)
+    e1, chunks = run_gpu(ann.ref_texts(), ann.chr_names, ann.chr_lens, batches)
+    n_frag = sum(b.n_frag for b in batches)
+    whole = synth_world.sort_by_coordinate(synth_world.concat_batches(batches))
+    del batches
+    e2, g = run_gpu(ann.ref_texts(), ann.chr_names, ann.chr_lens, [whole])
+    assert_results_equal(g, chunks, rel=0.0, what="50M pairs: sorted single batch vs unsorted chunks")
+    assert g["n_fragments"] == n_frag == st["n_pairs"] + st["n_singles"] == int(g["chr_cnt"].sum())
+    assert int(g["junc_cnt"].sum()) == g["n_junction_events"] > 10_000_000
+    # FragmentsInChr recounted with numpy
+    want = np.zeros((len(ann.chr_names), 2), np.int64)
+    np.add.at(want, (whole.frag_chr.astype(np.int64), (whole.frag_flags & 1).astype(np.int64)), 1)
+    assert np.array_equal(g["chr_cnt"].astype(np.int64), want)
+    # P6
+    tot = g["junc_cnt"].sum(axis=0).astype(np.int64)
+    key_l = g["junc_chr"].astype(np.int64) << 32 | g["junc_left"].astype(np.int64)
+    key_r = g["junc_chr"].astype(np.int64) << 32 | g["junc_right"].astype(np.int64)
+    name_to_idx = {n: i for i, n in enumerate(g["chr_names"])}
+    cols = [l.split("\t", 3)[:3] for l in ann.cover_bed.splitlines()]
+    in_l = np.array([name_to_idx[c[0]] << 32 | int(c[1]) for c in cols], np.int64)
+    in_r = np.array([name_to_idx[c[0]] << 32 | int(c[2]) for c in cols], np.int64)
+    for key, ik, col in ((key_l, in_l, "splice_left"), (key_r, in_r, "splice_right")):
+        uk, inv = np.unique(key, return_inverse=True)
+        sums = np.bincount(inv, weights=tot, minlength=len(uk)).astype(np.int64)
+        pos = np.searchsorted(uk, ik)
+        hit = (pos < len(uk)) & (uk[np.minimum(pos, len(uk) - 1)] == ik)
+        exp = np.where(hit, sums[np.minimum(pos, len(uk) - 1)], 0)
+        assert np.array_equal(exp, g["nondir"][col].astype(np.int64)), col
+    assert (g["nondir"]["intron_depth"] > 0).sum() > 50_000
