@@ -56,8 +56,9 @@ namespace {
 #ifndef STATS_MIN_WAVES
 #define STATS_MIN_WAVES 6
 #endif
-constexpr int kBinBits = 10;
-constexpr int kBins = 1 << kBinBits;
+#ifndef STATS_BITS_SMALL
+#define STATS_BITS_SMALL 10
+#endif
 constexpr int kQueries = 8;
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 constexpr uint32_t kMaxBlk = 64;    // measured blocks per descriptor chunk: one per lane
@@ -272,9 +273,10 @@ __device__ __forceinline__ double percentile_value(const PctRanks& q, uint32_t v
     return vk + ((double)q.rem / 100.0) * ((double)vb - vk);
 }
 
-template <int kThreads, int kMaxFlank, int kInFlight>
+template <int kThreads, int kMaxFlank, int kInFlight, int kBinBits>
 __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel(IntronTables T, const uint32_t* __restrict__ wg_off, uint32_t prof_slot) {
     constexpr int kWaves = kThreads / 64;
+    constexpr int kBins = 1 << kBinBits;                   // histogram bins per level of the rank select
     constexpr int kBinsPerThread = kBins / kThreads;
     static_assert(kBinsPerThread >= 1 && kBinsPerThread <= 16, "a thread's bins must fit one DPP row");
     __shared__ __align__(16) uint32_t s_cnt[kBins];
@@ -797,8 +799,8 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
 // walks records [wg_off[c][w], wg_off[c][w + 1]) (the host balanced the lists).  The 64-thread class keeps its flank
 // windows in a 64-entry LDS buffer: the host puts every intron into the 256-thread class when flank_len is larger.
 void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s) {
-    if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
-    if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+    if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
+    if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
 #ifdef STATS_PROF
     {
         static std::vector<uint32_t> h((size_t)kProfMax * 8);
