@@ -393,3 +393,54 @@ def test_full_size_properties_configs1():
         exp = np.where(hit, sums[np.minimum(pos, len(uk) - 1)], 0)
         assert np.array_equal(exp, g["nondir"][col].astype(np.int64)), col
     assert (g["nondir"]["intron_depth"] > 0).sum() > 50_000
+
+
+def test_many_measured_blocks_per_intron_and_limits():
+    """Introns whose measured part is cut into more blocks than one descriptor chunk of the statistics kernel holds
+    (64: one per lane): 150 and 65 blocks, flank windows spread over several blocks and over the chunk boundary, in
+    both size classes (a 30 kb intron for the 256-thread class), stranded and not, both flank modes.  And the stated
+    limit: an intron with 2^28 or more measured bases is refused at irf_chr_map_update."""
+    rng = np.random.default_rng(77)
+
+    def bed12(chrom, start, blocks, name):
+        end = blocks[-1][0] + blocks[-1][1]
+        return "%s\t%d\t%d\t%s\t0\t+\t%d\t%d\t255,0,0\t%d\t%s\t%s\n" % (
+            chrom, start, end, name, start, end, len(blocks), ",".join(str(l) for _, l in blocks),
+            ",".join(str(s - start) for s, _ in blocks))
+
+    def cut(start, n, lo, hi, gap_hi):
+        out, p = [], start
+        for _ in range(n):
+            l = int(rng.integers(lo, hi))
+            out.append((p, l))
+            p += l + int(rng.integers(1, gap_hi))
+        return out
+    b150 = cut(1000, 150, 3, 30, 6)                  # tiny blocks: the first window alone spans a dozen of them
+    b65 = cut(20000, 65, 20, 90, 10)
+    b200 = cut(40000, 200, 100, 220, 30)             # ~30 kb measured: 256-thread class
+    cover = bed12("chrA", 1000, b150, "G1/E1/+/1/a/b/clean") + bed12("chrA", 20000, b65, "G2/E2/-/1/a/b/clean") + \
+        bed12("chrA", 40000, b200, "G3/E3/+/1/a/b/clean")
+    ends = [b150[-1][0] + b150[-1][1], b65[-1][0] + b65[-1][1], b200[-1][0] + b200[-1][1]]
+    sj = "chrA\t1000\t%d\t+\nchrA\t20000\t%d\t-\n" % (ends[0], ends[1])
+    sp = "chrA\t1000\t+\nchrA\t%d\t+\nchrA\t20000\t-\n" % ends[0]
+    roi = "chrA\t90000\t95000\tR0\n"
+    names, lens = ["chrA"], [100000]
+    recs = []
+    for k in range(30000):
+        s = int(rng.integers(500, 80000))
+        recs.append(dict(ref_id=0, pos=s, flag=0x10 if rng.random() < 0.3 else 0, cigar="%dM" % int(rng.integers(20, 400))))
+    for k in range(40):
+        recs.append(dict(ref_id=0, pos=950, flag=0, cigar="50M%dN30M" % (ends[0] - 1000)))
+    names_, lens_, batch = read_batch(records_to_bam(names, lens, recs))
+    refs = (cover, sj, sp, roi)
+    for over in (dict(), dict(flank_use_measured=0), dict(flank_len=300, flank_offset=2), dict(dir_ratio=0)):
+        e, g = run_gpu(refs, names, lens, split(batch, 3), **over)
+        o, c = run_orc(refs, names, lens, [batch], **over)
+        assert_results_equal(g, c, rel=0.0, what="many blocks %s" % over)
+    assert (g["nondir"]["intron_depth"] > 0).all() and g["nondir"]["splice_exact"][0] == 40
+    # the limit
+    big = "chrB\t10\t%d\tG/E/+/1/a/b/clean\t0\t+\t10\t%d\t0\t1\t%d\t0\n" % (10 + (1 << 28), 10 + (1 << 28), 1 << 28)
+    ref = engine.RefTables.from_texts((big, "", "", ""))
+    eng = engine.Engine(ref)
+    with pytest.raises(engine.IrfError):
+        eng.chr_map_update(["chrB"], [300_000_000])
