@@ -94,7 +94,6 @@ struct Lds {
     int32_t lcnt[kLines][16];
     uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
     uint32_t jcnt[2][kJCache];
-    uint2 jpos[kJCache];               // plane positions of the junction's two difference events
     uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_pos32
     uint32_t pcnt[2][kPCache];
     unsigned long long nq[kNovelQ];
@@ -157,22 +156,18 @@ __device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsign
     }
 }
 
-// n reads of strand dir on known junction idx (difference events at plane positions cl / cr): the chunk's LDS
-// counter (true), or straight to the table (false: the caller then emits the reads' difference events itself)
-__device__ __forceinline__ bool junction_add(const CountTables& T, Lds& S, uint32_t idx, uint32_t dir, uint32_t n, uint64_t cl, uint64_t cr) {
+// n reads of strand dir on known junction idx: the chunk's LDS counter, or (slot taken by another junction) straight to
+// the table.  The counter also stands for the reads' two difference events next to the junction: they are applied once
+// per junction and sample by known_junction_depth_kernel at finalize, not once per read (or per chunk) here.
+__device__ __forceinline__ void junction_add(const CountTables& T, Lds& S, uint32_t idx, uint32_t dir, uint32_t n) {
     const uint32_t slot = idx & (kJCache - 1u);
     uint32_t tag = S.jtag[slot];
     if (tag == kEmpty) {
         const uint32_t old = atomicCAS(&S.jtag[slot], kEmpty, idx);
         tag = old == kEmpty ? idx : old;
     }
-    if (tag == idx) {
-        S.jpos[slot] = make_uint2((uint32_t)cl, (uint32_t)cr);      // every writer of the slot writes the same pair
-        atomicAdd(&S.jcnt[dir][slot], n);
-        return true;
-    }
-    atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + T.known_kjidx[idx]], n);
-    return false;
+    if (tag == idx) atomicAdd(&S.jcnt[dir][slot], n);
+    else atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + T.known_kjidx[idx]], n);
 }
 
 __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables T, BatchDev B) {
@@ -313,7 +308,6 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         const uint32_t kb0 = S.off[0], kb1 = S.off[kChunk];
         const unsigned long long win = S.win;
         const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
-        const bool fold_ok = T.plane_stride <= 0xffffffffull;       // the junction cache keeps plane positions as uint32
         uint32_t wmax = 0;
         const uint32_t g_lastb = B.n_blk ? (B.n_blk - 1u) >> 2 : 0u;
         // The block columns of an iteration are loaded one iteration ahead (the loads of the first iteration are issued
@@ -449,15 +443,12 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             CPROF(2);
             // JunctionCount on known junctions: the junction's LDS counter (same-address LDS atomics of a wave are
             // serialised by the hardware at about a lane per clock: cheaper than electing leaders in software).
-            // folded = the junction's counter now also stands for this read's two difference events
+            // folded = the junction's counter also stands for this read's two difference events (applied at finalize)
             bool folded[kVec];
 #pragma unroll
             for (int j = 0; j < kVec; j++) {
-                folded[j] = false;
-                if (hit[j] != kEmpty) {
-                    folded[j] = junction_add(T, S, hit[j], (fbv[j] & kFragDir) ? 1u : 0u, 1u, plane_of(T, ee[j].x, gbe[j]),
-                                             plane_of(T, es[j + 1].x, gbs[j + 1])) && fold_ok;
-                }
+                folded[j] = hit[j] != kEmpty && !(T.ablate & 64u);
+                if (hit[j] != kEmpty) junction_add(T, S, hit[j], (fbv[j] & kFragDir) ? 1u : 0u, 1u);
             }
             CPROF(3);
             // difference events, SpansPoint, novel junctions
@@ -536,7 +527,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         CPROF(4);
 
         // ---------------- 3. flush the LDS accumulators ----------------
-        // 3a. the junction cache: counters to the table, the junctions' difference events into window / line cache
+        // 3a. the junction cache and the SpansPoint cache: counters to the tables
         const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ;
         if (tid == 0 && nq) S.nq_base = atomicAdd(T.junc_count, (unsigned long long)nq);
         for (uint32_t e = tid; e < kJCache; e += kThreads) {
@@ -544,11 +535,6 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             if (idx != kEmpty) {
                 const uint32_t c0 = S.jcnt[0][e], c1 = S.jcnt[1][e];
                 const uint32_t row = T.known_kjidx[idx];
-                const uint2 pos = S.jpos[e];
-                if (!(T.ablate & 1u) && fold_ok) {
-                    if (c0) { depth_event(T, S, win, use_win, pos.x, 0u, -(int)c0, wmax); depth_event(T, S, win, use_win, pos.y, 0u, (int)c0, wmax); }
-                    if (c1) { depth_event(T, S, win, use_win, pos.x, 1u, -(int)c1, wmax); depth_event(T, S, win, use_win, pos.y, 1u, (int)c1, wmax); }
-                }
                 if (c0) atomicAdd(&T.known_cnt[row], c0);
                 if (c1) atomicAdd(&T.known_cnt[(uint64_t)T.n_kj + row], c1);
                 S.jtag[e] = kEmpty; S.jcnt[0][e] = 0; S.jcnt[1][e] = 0;
@@ -623,7 +609,33 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
     }
 }
 
+// Every read on a known junction skipped two difference events in the count kernel (the end of the block before the
+// junction, the start of the block after it): they are applied here, once per junction and strand, from the junction's
+// counter.  Must run after the last count kernel of the sample and before the carries are scanned.
+__global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= T.n_known || (T.ablate & (1u | 64u))) return;
+    const uint64_t key = T.known_keys[i];
+    const uint64_t gl = key >> kJuncSpanBits, gr = gl + (key & ((1ull << kJuncSpanBits) - 1ull));
+    const uint32_t row = T.known_kjidx[i];
+    const uint64_t cl = plane_coord(T.pmap, gl), cr = plane_coord(T.pmap, gr);
+#pragma unroll
+    for (uint32_t dir = 0; dir < 2u; dir++) {
+        const int c = (int)T.known_cnt[(uint64_t)dir * T.n_kj + row];
+        if (!c) continue;
+        __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cl, -c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cr, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seg_add(T, dir, cl, -c);
+        seg_add(T, dir, cr, c);
+    }
+}
+
 }   // namespace
+
+void launch_known_junction_depth(const CountTables& T, hipStream_t s) {
+    if (T.n_known == 0) return;
+    hipLaunchKernelGGL(known_junction_depth_kernel, dim3((T.n_known + 255u) / 256u), dim3(256), 0, s, T);
+}
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;

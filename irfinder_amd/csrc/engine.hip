@@ -762,6 +762,7 @@ int irf_ctx::finalize() {
     // Everything that needs no answer from the device is queued before the first synchronisation: the depth carries
     // (exclusive scan of the per-segment sums the count kernel kept next to the planes) and the known-junction
     // lookups with the strandedness vote (known junctions were counted in place; novel ones never vote).
+    dev::launch_known_junction_depth(count_tables(), stream);
     if (getenv("IRF_RESCAN_PLANES")) dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_seg_sum.p, stream);     // diagnostic: recompute the sums from the planes
     dev::launch_exclusive_scan_u32(d_seg_sum.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[1], stream));

@@ -46,7 +46,7 @@ struct CountTables {
     uint32_t sp_min_len;       // block is considered only if len > sp_min_len (= L + R)
     uint32_t sp_lo_add;        // candidates are the points in [bs + sp_lo_add, be - sp_hi_sub]
     uint32_t sp_hi_sub;
-    uint32_t ablate;           // diagnostic only (IRF_ABLATE env): bit0 depth, 1 SpansPoint, 2 ROI, 3 junction, 4 chr
+    uint32_t ablate;           // diagnostic only (IRF_ABLATE env): bit0 depth, 1 SpansPoint, 2 ROI, 3 junction, 4 chr, 6 no folding of known-junction events
     uint64_t plane_stride;     // elements per strand plane of the difference array (compact coordinates)
     uint64_t full_size;        // size of the full coordinate space (chr_base + pos); junction keys, point / junction buckets
     const uint32_t* pmap;      // full -> plane coordinates, one entry per 512-position bucket; nullptr = identity
@@ -100,6 +100,9 @@ struct BatchDev {
 };
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s);
+// difference events of the reads on known junctions, from the junction counters: after the sample's last count kernel,
+// before the carry scan (once per sample)
+void launch_known_junction_depth(const CountTables& T, hipStream_t s);
 
 // ---- scans ----------------------------------------------------------------
 constexpr uint32_t kScanTile = 4096;
