@@ -121,6 +121,8 @@ struct irf_ctx {
     DevBuf<uint32_t> d_stats_wg_off[2];
     DevBuf<uint64_t> d_us_pos, d_ue_pos, d_known_keys;
     DevBuf<uint8_t> d_known_dir;
+    DevBuf<int32_t> d_known_us_idx, d_known_ue_idx; // per known key: position of its ends among the intron starts / ends
+    std::vector<uint64_t> known_keys_h;
     DevBuf<uint32_t> d_known_kjidx, d_known_cnt;   // known-junction rows and their [2][n_kj] counters
     uint32_t n_kj = 0;
     unsigned long long votes[2] = {0, 0};
@@ -446,6 +448,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             TRY(upload(this, d_bkt, bk));
             std::vector<uint32_t>().swap(sp_bucket_h);
         }
+        known_keys_h = kkeys;
         TRY(upload(this, d_known_keys, kkeys));
         TRY(upload(this, d_known_dir, kdir));
         TRY(upload(this, d_known_kjidx, krow));
@@ -507,6 +510,18 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             uei[i] = (int32_t)(std::lower_bound(ue.begin(), ue.end(), ge[i]) - ue.begin());
         }
         n_us = (uint32_t)us.size(); n_ue = (uint32_t)ue.size();
+        {
+            std::vector<int32_t> kus(known_keys_h.size(), -1), kue(known_keys_h.size(), -1);
+            for (size_t k = 0; k < known_keys_h.size(); k++) {
+                const uint64_t gl = known_keys_h[k] >> dev::kJuncSpanBits, gr = gl + (known_keys_h[k] & ((1ull << dev::kJuncSpanBits) - 1ull));
+                auto a = std::lower_bound(us.begin(), us.end(), gl);
+                if (a != us.end() && *a == gl) kus[k] = (int32_t)(a - us.begin());
+                auto b = std::lower_bound(ue.begin(), ue.end(), gr);
+                if (b != ue.end() && *b == gr) kue[k] = (int32_t)(b - ue.begin());
+            }
+            TRY(upload(this, d_known_us_idx, kus)); TRY(upload(this, d_known_ue_idx, kue));
+            std::vector<uint64_t>().swap(known_keys_h);
+        }
         // one record per intron, laid out by size class and workgroup (kernels.h: StatsClasses): inside a class the
         // introns go, longest first, to the workgroup with the least work so far (cost = segments + a fixed part)
         {
@@ -774,6 +789,7 @@ int irf_ctx::finalize() {
     J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
     J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
     J.known_keys = d_known_keys.p; J.known_kjidx = d_known_kjidx.p; J.known_dir = d_known_dir.p;
+    J.known_us_idx = d_known_us_idx.p; J.known_ue_idx = d_known_ue_idx.p;
     J.n_known = n_known_dev; J.n_kj = n_kj; J.known_cnt = d_known_cnt.p;
     J.dir_votes = d_scalars.p + 3;
     dev::launch_known_lookups(J, stream);

@@ -143,6 +143,8 @@ struct JuncLookupTables {
     const uint64_t* known_keys;  // sorted (global_left << 28 | span) of ref-sj junctions on owned chromosomes
     const uint32_t* known_kjidx;
     const uint8_t* known_dir;    // per known_keys entry: 1 '-', 2 '+', 0/3 unknown
+    const int32_t* known_us_idx; // per known_keys entry: index of its left end in ustart_pos / right end in uend_pos, -1: none
+    const int32_t* known_ue_idx;
     uint32_t n_known, n_kj;
     const uint32_t* known_cnt;   // [2][n_kj]
     unsigned long long* dir_votes;   // [2]: same, opposite (JunctionCount::Directional)

@@ -160,15 +160,13 @@ __global__ __launch_bounds__(kThreads) void known_lookups_kernel(JuncLookupTable
         const uint32_t row = J.known_kjidx[k];
         const uint32_t c0 = J.known_cnt[row], c1 = J.known_cnt[(uint64_t)J.n_kj + row];
         if (c0 | c1) {
-            const uint64_t key = J.known_keys[k];
-            const uint64_t gleft = key >> kJuncSpanBits;
-            const uint64_t span = key & ((1ull << kJuncSpanBits) - 1ull);
-            const int64_t a = find_u64(J.ustart_pos, J.n_ustart, gleft);
+            // where the junction's ends sit among the intron starts / ends was looked up by the host (static)
+            const int64_t a = J.known_us_idx[k];
             if (a >= 0) {
                 if (c0) atomicAdd(&J.left_cnt[(uint64_t)a], c0);
                 if (c1) atomicAdd(&J.left_cnt[(uint64_t)J.n_ustart + (uint64_t)a], c1);
             }
-            const int64_t b = find_u64(J.uend_pos, J.n_uend, gleft + span);
+            const int64_t b = J.known_ue_idx[k];
             if (b >= 0) {
                 if (c0) atomicAdd(&J.right_cnt[(uint64_t)b], c0);
                 if (c1) atomicAdd(&J.right_cnt[(uint64_t)J.n_uend + (uint64_t)b], c1);
