@@ -320,6 +320,57 @@ int irf_cigar2block(const uint32_t* cigar, uint32_t n_cigar,
                     uint32_t* starts, uint32_t* lens, uint32_t cap,
                     uint32_t* n_blocks, uint32_t* genome_len);
 
+/* ------------------------------------------------------------------------ */
+/* Device reader (SURVEY.md §8 f, row N1).  Replaces the `gzip -cd sample.bam |`
+ * stage of ⟨upstream⟩ bin/IRFinder together with BAM2blocks (⟨upstream⟩
+ * BAM2blocks.cpp: processAll, processPair, processSingle, cigar2block): the
+ * caller feeds COMPRESSED BGZF bytes (host memory, any chunking); members are
+ * inflated and CRC-checked, records located, mates paired and fragments
+ * assembled on the device.  The result of a feed is a DEVICE-resident
+ * irf_batch — equal, column by column, to what irf_reader_* yields for the
+ * same bytes — that goes straight into irf_submit_batch of a context on the
+ * same device.  params.mate_join must be 0 (upstream's pairing: the next record
+ * is the mate); the BAM header must be complete before the first batch appears.
+ * The batch of a feed stays valid until the next-but-one feed (two slots): call
+ * irf_sync on the consuming context before feeding twice more.                */
+typedef struct irf_dreader irf_dreader;
+
+typedef struct irf_dreader_timing {     /* sums over all feeds, HIP events on the reader's stream */
+    float h2d_ms;         /* compressed bytes + member table to the device                  */
+    float inflate_ms;     /* bgzf_inflate_kernel                                              */
+    float crc_ms;         /* bgzf_crc_kernel                                                  */
+    float chain_ms;       /* record starts: guess, verify rounds, scan (includes host syncs)  */
+    float assemble_ms;    /* record index, pairing state, count pass, scans, write pass       */
+    float reserved;
+    uint64_t bytes_in;        /* compressed bytes consumed                                    */
+    uint64_t bytes_inflated;
+    uint64_t n_members;
+} irf_dreader_timing;
+
+int irf_dreader_create(const irf_params* params, int device, irf_dreader** out);
+void irf_dreader_destroy(irf_dreader* r);
+const char* irf_dreader_last_error(const irf_dreader* r);
+int irf_dreader_feed(irf_dreader* r, const uint8_t* bgzf, size_t len);
+int irf_dreader_header(const irf_dreader* r, const char* const** names, const uint32_t** lens);
+/* Fragments of the LAST feed (possibly none), device-resident.               */
+int irf_dreader_batch(const irf_dreader* r, irf_batch* out);
+int irf_dreader_finish(irf_dreader* r);      /* EOF: truncated member / record, dangling mate */
+int irf_dreader_get_stats(const irf_dreader* r, irf_reader_stats* out);
+int irf_dreader_get_timing(const irf_dreader* r, irf_dreader_timing* out);
+
+/* Waits until everything submitted to the context has been processed (its
+ * compute stream is idle): device-resident batches may then be overwritten.
+ * No upstream counterpart (upstream is synchronous).                         */
+int irf_sync(irf_ctx* ctx);
+/* Device -> host copy for callers without a HIP runtime binding of their own
+ * (parity tests read the columns of a device-resident batch with it).         */
+int irf_copy_to_host(void* dst_host, const void* src_device, size_t bytes);
+/* Pure function of the device reader, for parity tests: inflates a buffer of
+ * whole BGZF members (CRC-checked) on the device into host memory.
+ * IRF_E_PARSE: malformed / corrupt member; IRF_E_RANGE: out_cap too small
+ * (*out_len is set to the size needed).                                       */
+int irf_gpu_bgzf_inflate(int device, const uint8_t* bgzf, size_t len, uint8_t* out, size_t out_cap, size_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

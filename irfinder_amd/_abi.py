@@ -105,6 +105,11 @@ class IrfReaderStats(C.Structure):
                                           "n_pairs_intersect", "n_pairs_long", "n_skipped", "n_error")]
 
 
+class IrfDreaderTiming(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("h2d_ms", "inflate_ms", "crc_ms", "chain_ms", "assemble_ms", "reserved")] + \
+               [(n, C.c_uint64) for n in ("bytes_in", "bytes_inflated", "n_members")]
+
+
 class IrfLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("plane_positions", "full_positions", "measured_positions", "junction_capacity")]
 

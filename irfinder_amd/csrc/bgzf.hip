@@ -1,0 +1,450 @@
+// bgzf.hip — BGZF members -> inflated BAM stream, on the device (gfx950).
+//
+// Stands where ⟨upstream⟩ bin/IRFinder runs `gzip -cd` in front of the engine (SURVEY §3.1, §8 f N1).  BGZF (SAM
+// spec §4.1) is a concatenation of independent gzip members of at most 64 KiB of inflated data each, so the file is
+// block-parallel: one LANE inflates one member (RFC 1951: stored, fixed and dynamic Huffman blocks, written here from
+// the RFC — zlib stays on the host, for the host reader only).
+//
+// A lane's Huffman state lives in LDS: canonical decoding needs, per code length L, the left-justified upper limit of
+// the codes of that length and the offset of their symbols in the length-sorted symbol list — 15 + 15 + 288 entries for
+// literal/length, 15 + 15 + 32 for distances = 380 uint16 per lane, interleaved by lane (element j of lane l at
+// [j][l]), 47.5 KiB per 64-lane workgroup, three workgroups per CU.  A code is decoded by a 4-step binary search over the
+// limits (15 peeked bits, bit-reversed: DEFLATE packs Huffman codes most-significant bit first into a
+// least-significant-bit-first stream).  The code-length alphabet of a dynamic block (19 symbols, <= 7 bits) is decoded
+// from registers; the code lengths are read TWICE (count per length, then place the symbols), which saves a 320-entry
+// per-lane length array.
+//
+// Output: literal bytes collect in a register and leave as aligned dwords; matches copy 4 bytes per round trip when
+// the distance allows.  The CRC-32 of every member is checked by a second kernel (one wave per member, 64 slices
+// combined with x^(8n) mod P), so a corrupt file is refused exactly where the host reader refuses it.
+#include "dreader_kernels.h"
+
+namespace irf {
+namespace dev {
+
+namespace {
+
+constexpr int LIT_SYM = 0, DIST_SYM = 288, LIT_LIM = 320, LIT_BASE = 335, DIST_LIM = 350, DIST_BASE = 365, TAB_U16 = 380;
+constexpr int kLanes = 64;
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ void st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+struct Bits {
+    const uint8_t* p;    // next input byte to load
+    uint64_t bb;         // bit buffer, next bit = bit 0
+    uint32_t bc;         // valid bits in bb
+    __device__ __forceinline__ void refill() {           // afterwards bc >= 33
+        if (bc <= 32) {
+            bb |= (uint64_t)ld32u(p) << bc;
+            p += 4;
+            bc += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+#define TAB(j) s_tab[(j) * kLanes + lane]
+
+// canonical Huffman: smallest length whose left-justified limit exceeds the next 15 bits
+__device__ __forceinline__ int decode_sym(const uint16_t* s_tab, uint32_t lane, int LIM, int BASE, int SYM, Bits& b) {
+    const uint32_t v = __brev(b.peek(15)) >> 17;
+    uint32_t pos = 0;
+    if (TAB(LIM + 7) <= v) pos = 8;
+    if (TAB(LIM + pos + 3) <= v) pos += 4;
+    if (TAB(LIM + pos + 1) <= v) pos += 2;
+    if (TAB(LIM + pos) <= v) pos += 1;
+    if (pos >= 15) return -1;
+    const uint32_t idx = (uint16_t)(TAB(BASE + pos) + (v >> (14 - pos)));
+    b.drop(pos + 1);
+    return TAB(SYM + idx);
+}
+
+// counts per length (in the LIM slots) -> limits; BASE slots = first free symbol slot of each length (for placing).
+// Returns 0, or -1 for an over-subscribed set or an incomplete one (zlib accepts an incomplete set only when its longest
+// code has one bit).
+__device__ int limits_from_counts(uint16_t* s_tab, uint32_t lane, int LIM, int BASE) {
+    uint32_t first = 0, offs = 0, maxlen = 0;
+    for (uint32_t L = 1; L <= 15; L++) {
+        const uint32_t c = TAB(LIM + L - 1);
+        if (first + c > (1u << L)) return -1;
+        if (c) maxlen = L;
+        TAB(BASE + L - 1) = (uint16_t)offs;
+        TAB(LIM + L - 1) = (uint16_t)((first + c) << (15 - L));
+        offs += c;
+        first = (first + c) << 1;
+    }
+    // first == 2 * (codes used at length 15); complete iff that is 2^16
+    if (first != (1u << 16) && maxlen > 1) return -1;
+    return 0;
+}
+
+// BASE slots -> (offset of the length's symbols) - (first code of the length), the constant decode_sym adds to a code
+__device__ void bases_from_limits(uint16_t* s_tab, uint32_t lane, int LIM, int BASE) {
+    uint32_t first = 0, offs = 0;
+    for (uint32_t L = 1; L <= 15; L++) {
+        const uint32_t end = (uint32_t)TAB(LIM + L - 1) >> (15 - L);
+        TAB(BASE + L - 1) = (uint16_t)(offs - first);
+        offs += end - first;
+        first = end << 1;
+    }
+}
+
+__device__ __forceinline__ void zero_counts(uint16_t* s_tab, uint32_t lane, int LIM) {
+    for (int L = 0; L < 15; L++) TAB(LIM + L) = 0;
+}
+
+__device__ __forceinline__ void place_sym(uint16_t* s_tab, uint32_t lane, int BASE, int SYM, uint32_t len, uint32_t sym) {
+    const uint32_t k = TAB(BASE + len - 1);
+    TAB(BASE + len - 1) = (uint16_t)(k + 1);
+    TAB(SYM + k) = (uint16_t)sym;
+}
+
+__device__ __forceinline__ uint32_t fixed_lit_len(uint32_t s) { return s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u; }
+
+__device__ void build_fixed(uint16_t* s_tab, uint32_t lane) {
+    zero_counts(s_tab, lane, LIT_LIM);
+    zero_counts(s_tab, lane, DIST_LIM);
+    TAB(LIT_LIM + 6) = 24; TAB(LIT_LIM + 7) = 152; TAB(LIT_LIM + 8) = 112;
+    TAB(DIST_LIM + 4) = 32;
+    limits_from_counts(s_tab, lane, LIT_LIM, LIT_BASE);
+    limits_from_counts(s_tab, lane, DIST_LIM, DIST_BASE);
+    for (uint32_t s = 0; s < 288; s++) place_sym(s_tab, lane, LIT_BASE, LIT_SYM, fixed_lit_len(s), s);
+    for (uint32_t s = 0; s < 32; s++) place_sym(s_tab, lane, DIST_BASE, DIST_SYM, 5, s);
+    bases_from_limits(s_tab, lane, LIT_LIM, LIT_BASE);
+    bases_from_limits(s_tab, lane, DIST_LIM, DIST_BASE);
+}
+
+// the code-length alphabet, in registers: counts per length (5 bits each), symbols sorted by (length, symbol) (5 bits each)
+struct ClCode { uint64_t counts, sym_lo, sym_hi; };
+
+__device__ __forceinline__ int cl_decode(const ClCode& c, Bits& b) {
+    const uint32_t v = __brev(b.peek(7)) >> 25;
+    uint32_t first = 0, index = 0;
+#pragma unroll
+    for (uint32_t L = 1; L <= 7; L++) {
+        const uint32_t n = (uint32_t)(c.counts >> (5 * (L - 1))) & 31u;
+        const uint32_t code = v >> (7 - L);
+        if (code - first < n) {
+            const uint32_t k = index + code - first;
+            b.drop(L);
+            return (int)(k < 12 ? (c.sym_lo >> (5 * k)) & 31u : (c.sym_hi >> (5 * (k - 12))) & 31u);
+        }
+        index += n;
+        first = (first + n) << 1;
+    }
+    return -1;
+}
+
+// reads the hlit + hdist code lengths of a dynamic block: PLACE = false counts them per length (LIM slots),
+// PLACE = true puts every symbol into its slot of the length-sorted lists.  Returns 0 / -1.
+template <bool PLACE>
+__device__ int read_code_lengths(uint16_t* s_tab, uint32_t lane, Bits& b, const ClCode& cl, uint32_t hlit, uint32_t hdist,
+                                 bool* has_eob) {
+    const uint32_t total = hlit + hdist;
+    uint32_t s = 0, prev = 0;
+    while (s < total) {
+        b.refill();
+        const int sym = cl_decode(cl, b);
+        if (sym < 0) return -1;
+        uint32_t rep = 1, val = (uint32_t)sym;
+        if (sym == 16) {
+            if (s == 0) return -1;
+            val = prev;
+            rep = 3 + b.take(2);
+        } else if (sym == 17) {
+            val = 0;
+            rep = 3 + b.take(3);
+        } else if (sym == 18) {
+            val = 0;
+            rep = 11 + b.take(7);
+        }
+        if (s + rep > total) return -1;
+        if (val) {
+            for (uint32_t r = 0; r < rep; r++) {
+                const uint32_t t = s + r;
+                const bool lit = t < hlit;
+                if (PLACE) {
+                    if (lit) place_sym(s_tab, lane, LIT_BASE, LIT_SYM, val, t);
+                    else place_sym(s_tab, lane, DIST_BASE, DIST_SYM, val, t - hlit);
+                } else {
+                    const int slot = (lit ? LIT_LIM : DIST_LIM) + (int)val - 1;
+                    TAB(slot) = (uint16_t)(TAB(slot) + 1);
+                    if (t == 256) *has_eob = true;
+                }
+            }
+        }
+        s += rep;
+        prev = val;
+    }
+    return 0;
+}
+
+// order in which the code-length code lengths are stored (RFC 1951 §3.2.7), 5 bits each
+constexpr uint64_t kClOrderLo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                                10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+constexpr uint64_t kClOrderHi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+
+__device__ int build_dynamic(uint16_t* s_tab, uint32_t lane, Bits& b) {
+    b.refill();
+    const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return -1;
+    uint64_t cll = 0;     // 3 bits per code-length symbol
+    for (uint32_t i = 0; i < hclen; i++) {
+        b.refill();
+        const uint32_t sym = (uint32_t)(i < 12 ? kClOrderLo >> (5 * i) : kClOrderHi >> (5 * (i - 12))) & 31u;
+        cll |= (uint64_t)b.take(3) << (3 * sym);
+    }
+    ClCode cl{0, 0, 0};
+    {
+        uint32_t n = 0;
+        int left = 1;
+        for (uint32_t L = 1; L <= 7; L++) {
+            uint32_t c = 0;
+            for (uint32_t sym = 0; sym < 19; sym++) {
+                if (((cll >> (3 * sym)) & 7u) == L) {
+                    if (n < 12) cl.sym_lo |= (uint64_t)sym << (5 * n);
+                    else cl.sym_hi |= (uint64_t)sym << (5 * (n - 12));
+                    n++;
+                    c++;
+                }
+            }
+            cl.counts |= (uint64_t)c << (5 * (L - 1));
+            left = (left << 1) - (int)c;
+            if (left < 0) return -1;
+        }
+        if (left > 0) return -1;          // zlib: an incomplete code-length code is an error
+    }
+    zero_counts(s_tab, lane, LIT_LIM);
+    zero_counts(s_tab, lane, DIST_LIM);
+    bool has_eob = false;
+    const Bits at_lengths = b;
+    if (read_code_lengths<false>(s_tab, lane, b, cl, hlit, hdist, &has_eob) != 0) return -1;
+    if (!has_eob) return -1;
+    if (limits_from_counts(s_tab, lane, LIT_LIM, LIT_BASE) != 0) return -1;
+    if (limits_from_counts(s_tab, lane, DIST_LIM, DIST_BASE) != 0) return -1;
+    b = at_lengths;
+    read_code_lengths<true>(s_tab, lane, b, cl, hlit, hdist, &has_eob);
+    bases_from_limits(s_tab, lane, LIT_LIM, LIT_BASE);
+    bases_from_limits(s_tab, lane, DIST_LIM, DIST_BASE);
+    return 0;
+}
+
+__global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __restrict__ in, const BgzfMember* __restrict__ members,
+                                                              uint32_t n_members, uint8_t* out, uint32_t* __restrict__ status) {
+    __shared__ uint16_t s_tab[TAB_U16 * kLanes];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t mi = blockIdx.x * kLanes + lane;
+    if (mi >= n_members) return;
+    const BgzfMember m = members[mi];
+    if (m.isize == 0) {                    // the 28-byte EOF marker and other empty members (the host reader skips them too)
+        status[mi] = BGZF_OK;
+        return;
+    }
+    const uint8_t* const in0 = in + m.in_off;
+    const uint8_t* const in_lim = in0 + m.clen + 8;      // a valid stream never loads beyond this (then 4 more bytes are read)
+    Bits b{in0, 0, 0};
+    uint8_t* const obase = out + m.out_off;
+    const uint32_t isize = m.isize;
+    uint32_t op = 0, pend = 0, pn = 0;
+    bool bad = false, last = false;
+
+    auto consumed_bits = [&]() -> uint64_t { return (uint64_t)(b.p - in0) * 8ull - b.bc; };
+    auto put = [&](uint32_t byte) {
+        uint8_t* a = obase + op;
+        if (pn == 0 && (reinterpret_cast<uintptr_t>(a) & 3u)) {
+            *a = (uint8_t)byte;
+        } else {
+            pend |= byte << (8 * pn);
+            if (++pn == 4) {
+                *reinterpret_cast<uint32_t*>(a - 3) = pend;
+                pend = 0;
+                pn = 0;
+            }
+        }
+        op++;
+    };
+    auto flush = [&]() {
+        uint8_t* a = obase + op - pn;
+        for (uint32_t k = 0; k < pn; k++) a[k] = (uint8_t)(pend >> (8 * k));
+        pend = 0;
+        pn = 0;
+    };
+
+    while (!bad && !last) {
+        if (consumed_bits() > (uint64_t)m.clen * 8ull) { bad = true; break; }
+        b.refill();
+        last = b.take(1) != 0;
+        const uint32_t btype = b.take(2);
+        if (btype == 0) {
+            b.drop(b.bc & 7u);
+            b.refill();
+            const uint32_t len = b.take(16), nlen = b.take(16);
+            if ((len ^ nlen) != 0xffffu || op + len > isize || consumed_bits() + 8ull * len > (uint64_t)m.clen * 8ull) { bad = true; break; }
+            for (uint32_t k = 0; k < len; k++) {
+                b.refill();
+                put(b.take(8));
+            }
+            continue;
+        }
+        if (btype == 3) { bad = true; break; }
+        if (btype == 1) build_fixed(s_tab, lane);
+        else if (build_dynamic(s_tab, lane, b) != 0) { bad = true; break; }
+        while (true) {
+            if (b.p > in_lim) { bad = true; break; }
+            b.refill();
+            int sym = decode_sym(s_tab, lane, LIT_LIM, LIT_BASE, LIT_SYM, b);
+            if (sym < 0) { bad = true; break; }
+            if (sym < 256) {
+                if (op >= isize) { bad = true; break; }
+                put((uint32_t)sym);
+                continue;
+            }
+            if (sym == 256) break;
+            sym -= 257;
+            if (sym >= 29) { bad = true; break; }
+            uint32_t len;
+            if (sym < 8) len = 3u + (uint32_t)sym;
+            else if (sym == 28) len = 258u;
+            else {
+                const uint32_t e = ((uint32_t)sym - 4u) >> 2;
+                len = 3u + ((4u + ((uint32_t)sym & 3u)) << e) + b.take(e);
+            }
+            b.refill();
+            const int ds = decode_sym(s_tab, lane, DIST_LIM, DIST_BASE, DIST_SYM, b);
+            if (ds < 0 || ds >= 30) { bad = true; break; }
+            uint32_t dist;
+            if (ds < 4) dist = 1u + (uint32_t)ds;
+            else {
+                const uint32_t e = ((uint32_t)ds - 2u) >> 1;
+                dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + b.take(e);
+            }
+            if (dist > op || op + len > isize) { bad = true; break; }
+            flush();
+            uint8_t* dst = obase + op;
+            const uint8_t* src = dst - dist;
+            op += len;
+            if (dist >= 8) {
+                while (len >= 8) {
+                    const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
+                    st32u(dst, w0);
+                    st32u(dst + 4, w1);
+                    src += 8; dst += 8; len -= 8;
+                }
+            }
+            if (dist >= 4) {
+                while (len >= 4) {
+                    st32u(dst, ld32u(src));
+                    src += 4; dst += 4; len -= 4;
+                }
+            }
+            while (len) {
+                *dst++ = *src++;
+                len--;
+            }
+        }
+    }
+    flush();
+    if (!bad && (op != isize || consumed_bits() > (uint64_t)m.clen * 8ull)) bad = true;
+    status[mi] = bad ? BGZF_BAD_DEFLATE : BGZF_OK;
+}
+
+// ---- CRC-32 -------------------------------------------------------------------------------------------------------
+constexpr uint32_t kCrcPoly = 0xEDB88320u;
+struct CrcPowers { uint32_t x2n[32]; };       // x^(2^k) mod P, reflected (bit 31 = x^0)
+
+__host__ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & (0x80000000u >> i)) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+
+// One wave per member: lane l takes the l-th of 64 equal slices; crc(A||B) = crc(A) * x^(8|B|) + crc(B) (mod P), so the
+// member's CRC is the XOR over lanes of crc(slice) * x^(8 * bytes behind the slice).
+__global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict__ out, const BgzfMember* __restrict__ members,
+                                                       uint32_t n_members, uint32_t* status, CrcPowers pw) {
+    __shared__ uint32_t s_t[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+        s_t[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t mi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (mi >= n_members) return;
+    if (status[mi] != BGZF_OK) return;
+    const BgzfMember m = members[mi];
+    const uint32_t S = (m.isize + 63u) / 64u;
+    const uint32_t beg = min(lane * S, m.isize), end = min(beg + S, m.isize);
+    const uint8_t* p = out + m.out_off + beg;
+    uint32_t n = end - beg, c = 0xffffffffu;
+    while (n >= 4) {
+        const uint32_t w = ld32u(p);
+        c = s_t[(c ^ w) & 0xffu] ^ (c >> 8);
+        c = s_t[(c ^ (w >> 8)) & 0xffu] ^ (c >> 8);
+        c = s_t[(c ^ (w >> 16)) & 0xffu] ^ (c >> 8);
+        c = s_t[(c ^ (w >> 24)) & 0xffu] ^ (c >> 8);
+        p += 4; n -= 4;
+    }
+    while (n) {
+        c = s_t[(c ^ *p++) & 0xffu] ^ (c >> 8);
+        n--;
+    }
+    c = ~c;
+    uint32_t contrib = 0;
+    if (end > beg) {
+        const uint32_t tail = m.isize - end;
+        uint32_t pwr = 0x80000000u;
+        for (int k = 0; k < 17; k++)
+            if ((tail >> k) & 1u) pwr = crc_mulmod(pw.x2n[k + 3], pwr);
+        contrib = crc_mulmod(pwr, c);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) contrib ^= __shfl_xor(contrib, d);
+    if (lane == 0 && contrib != m.crc) status[mi] = BGZF_BAD_CRC;
+}
+
+__global__ __launch_bounds__(256) void first_bad_kernel(const uint32_t* __restrict__ status, uint32_t n, uint32_t* first_bad) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && status[i] != BGZF_OK) atomicMin(first_bad, i);
+}
+
+CrcPowers crc_powers() {
+    CrcPowers pw;
+    pw.x2n[0] = 0x40000000u;
+    for (int k = 1; k < 32; k++) pw.x2n[k] = crc_mulmod(pw.x2n[k - 1], pw.x2n[k - 1]);
+    return pw;
+}
+
+}   // namespace
+
+void launch_bgzf_inflate(const uint8_t* in, const BgzfMember* members, uint32_t n_members, uint8_t* out, uint32_t* status,
+                         hipStream_t s) {
+    if (!n_members) return;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_members + kLanes - 1) / kLanes), dim3(kLanes), 0, s, in, members, n_members, out,
+                       status);
+}
+
+void launch_bgzf_crc(const uint8_t* out, const BgzfMember* members, uint32_t n_members, uint32_t* status, hipStream_t s) {
+    if (!n_members) return;
+    static const CrcPowers pw = crc_powers();
+    hipLaunchKernelGGL(bgzf_crc_kernel, dim3((n_members + 3) / 4), dim3(256), 0, s, out, members, n_members, status, pw);
+}
+
+void launch_first_bad(const uint32_t* status, uint32_t n_members, uint32_t* first_bad, hipStream_t s) {
+    if (!n_members) return;
+    hipLaunchKernelGGL(first_bad_kernel, dim3((n_members + 255) / 256), dim3(256), 0, s, status, n_members, first_bad);
+}
+
+}   // namespace dev
+}   // namespace irf

@@ -1,0 +1,473 @@
+// dreader.hip — irf_dreader: the device reader (SURVEY §8 f N1) and its C ABI (include/irf.h, "Device reader").
+//
+// Stands where ⟨upstream⟩ bin/IRFinder pipes `gzip -cd sample.bam` into BAM2blocks::processAll: the host only locates
+// the BGZF members (one header hop per <= 64 KiB) and parses the BAM header; inflate, CRC check, record location, mate
+// pairing and fragment assembly run on the device and leave a DEVICE-resident irf_batch that goes straight into
+// irf_submit_batch — the records never exist in host memory.  Semantics = the host reader's (host/bam_reader.cpp),
+// params.mate_join = 0 (upstream's pairing: the next record is the mate).
+//
+// Per feed: [carry of the previous feed | inflated members] in one buffer; what is left behind the last complete
+// fragment unit (a partial record, or a first mate whose mate has not arrived) is the next feed's carry.
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/irf.h"
+#include "../host/bam_reader.h"
+#include "dreader_kernels.h"
+#include "kernels.h"
+
+namespace {
+
+namespace dev = irf::dev;
+
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    // grows geometrically (never shrinks); contents are NOT preserved
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = std::max<size_t>(n + n / 4, 256);
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+};
+
+struct OutSlot {
+    DBuf<uint32_t> frag_chr, frag_start, frag_end, frag_blk_off, blk_start, blk_len;
+    DBuf<uint8_t> frag_flags, blk_read;
+    uint32_t n_frag = 0, n_blk = 0;
+};
+
+}   // namespace
+
+struct irf_dreader {
+    irf_params P;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool failed = false;
+
+    // host side
+    std::vector<uint8_t> pending;            // compressed bytes not consumed yet (a partial member, or an incomplete header)
+    bool header_done = false;
+    bool header_skipped = false;             // the device has stepped over the header bytes
+    uint64_t header_len = 0;
+    std::vector<std::string> chr_names;
+    std::vector<uint32_t> chr_lens;
+    std::vector<const char*> chr_name_ptrs;
+    std::vector<irf::ZBlock> zblocks;
+    std::vector<dev::BgzfMember> members;
+    irf_reader_stats stats;
+    irf_dreader_timing timing;
+
+    // device side
+    DBuf<uint8_t> d_in, d_raw[2];
+    int cur = 0;
+    uint64_t carry_len = 0;                  // bytes at the front of d_raw[cur]
+    bool carry_dangling = false;             // the carry starts with a complete first mate that waits for its mate
+    bool carry_partial = false;              // ... and / or ends with an incomplete record
+    DBuf<dev::BgzfMember> d_members;
+    DBuf<uint32_t> d_status, d_count, d_seg_base, d_rec_nf, d_tile_last, d_tile_carry, d_fr, d_bl, d_ws;
+    DBuf<uint64_t> d_guess, d_exit, d_rec_off;
+    DBuf<unsigned long long> d_scal;         // [0] record error, [1 .. 1 + RS_COUNT) reader statistics
+    DBuf<uint32_t> d_flags;                  // [0] chain changed, [1] first bad member, [2] dangling
+    OutSlot out[2];
+    int out_cur = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    int fail(int code, const std::string& msg) { err = msg; failed = true; return code; }
+    int init();
+    int feed(const uint8_t* data, size_t len);
+    int process(size_t consumed_in);
+    int finish();
+    int host_header(size_t n_members_avail);
+};
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(IRF_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define MEM_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(IRF_E_NOMEM, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int irf_dreader::init() {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    memset(&stats, 0, sizeof stats);
+    memset(&timing, 0, sizeof timing);
+    MEM_TRY(d_scal.reserve(1 + dev::RS_COUNT));
+    MEM_TRY(d_flags.reserve(4));
+    return 0;
+}
+
+// The BAM header is needed on the host (irf_chr_map_update wants names and lengths before any batch): the leading
+// members are inflated with zlib until it is complete.  The device inflates them again with the rest and starts at
+// header_len.
+int irf_dreader::host_header(size_t n_avail) {
+    std::vector<uint8_t> raw;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return fail(IRF_E_NOMEM, "zlib: inflateInit2 failed");
+    int rc = 1;
+    for (size_t i = 0; i < n_avail && rc == 1; i++) {
+        const irf::ZBlock& b = zblocks[i];
+        if (b.isize) {
+            const size_t at = raw.size();
+            raw.resize(at + b.isize);
+            inflateReset(&zs);
+            zs.next_in = const_cast<Bytef*>(pending.data() + b.in_off);
+            zs.avail_in = (uInt)b.clen;
+            zs.next_out = raw.data() + at;
+            zs.avail_out = b.isize;
+            const int zr = inflate(&zs, Z_FINISH);
+            if (zr != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); return fail(IRF_E_PARSE, "BGZF: inflate failed"); }
+        }
+        size_t consumed = 0;
+        std::string e;
+        rc = irf::parse_bam_header(raw.data(), raw.size(), chr_names, chr_lens, consumed, e);
+        if (rc < 0) { inflateEnd(&zs); return fail(IRF_E_PARSE, e); }
+        if (rc == 0) header_len = consumed;
+    }
+    inflateEnd(&zs);
+    if (rc == 0) {
+        header_done = true;
+        chr_name_ptrs.clear();
+        for (auto& s : chr_names) chr_name_ptrs.push_back(s.c_str());
+    }
+    return 0;
+}
+
+int irf_dreader::feed(const uint8_t* data, size_t len) {
+    if (failed) return IRF_E_PARSE;
+    HIP_TRY(hipSetDevice(device));
+    pending.insert(pending.end(), data, data + len);
+    zblocks.clear();
+    size_t scan = 0, total_out = 0;
+    const std::string scan_error = irf::bgzf_locate(pending.data(), pending.size(), scan, total_out, zblocks);
+    if (!scan_error.empty()) return fail(IRF_E_PARSE, scan_error);
+    out[out_cur ^ 1].n_frag = out[out_cur ^ 1].n_blk = 0;
+    if (zblocks.empty()) { out_cur ^= 1; return 0; }
+    if (!header_done) {
+        int rc = host_header(zblocks.size());
+        if (rc != 0) return rc;
+        if (!header_done) { out_cur ^= 1; return 0; }    // wait for more members (nothing consumed)
+    }
+    return process(scan);
+}
+
+int irf_dreader::process(size_t consumed_in) {
+    const uint32_t n_members = (uint32_t)zblocks.size();
+    members.resize(n_members);
+    uint64_t total_out = 0;
+    for (uint32_t i = 0; i < n_members; i++) {
+        const irf::ZBlock& b = zblocks[i];
+        members[i] = dev::BgzfMember{b.in_off, carry_len + b.out_off, (uint32_t)b.clen, b.isize, b.crc, 0};
+        total_out += b.isize;
+    }
+    const uint64_t total = carry_len + total_out;
+    MEM_TRY(d_in.reserve(consumed_in + dev::kInflateSlack));
+    MEM_TRY(d_members.reserve(n_members));
+    MEM_TRY(d_status.reserve(n_members));
+    if (d_raw[cur].cap < total + 64) {
+        // grow, keeping the carry at the front
+        DBuf<uint8_t> bigger;
+        MEM_TRY(bigger.reserve(total + 64));
+        if (carry_len) HIP_TRY(hipMemcpyAsync(bigger.p, d_raw[cur].p, carry_len, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::swap(d_raw[cur].p, bigger.p);
+        std::swap(d_raw[cur].cap, bigger.cap);
+    }
+    uint8_t* const raw = d_raw[cur].p;
+    uint32_t* const f_changed = d_flags.p, *const f_first_bad = d_flags.p + 1, *const f_dangling = d_flags.p + 2;
+
+    HIP_TRY(hipEventRecord(ev[0], stream));
+    HIP_TRY(hipMemcpyAsync(d_in.p, pending.data(), consumed_in, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(d_in.p + consumed_in, 0, dev::kInflateSlack, stream));
+    HIP_TRY(hipMemcpyAsync(d_members.p, members.data(), sizeof(dev::BgzfMember) * n_members, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(f_first_bad, 0xff, 4, stream));
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    dev::launch_bgzf_inflate(d_in.p, d_members.p, n_members, raw, d_status.p, stream);
+    HIP_TRY(hipEventRecord(ev[2], stream));
+    dev::launch_bgzf_crc(raw, d_members.p, n_members, d_status.p, stream);
+    dev::launch_first_bad(d_status.p, n_members, f_first_bad, stream);
+    HIP_TRY(hipEventRecord(ev[3], stream));
+    HIP_TRY(hipGetLastError());
+    uint32_t first_bad = 0;
+    HIP_TRY(hipMemcpyAsync(&first_bad, f_first_bad, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (first_bad != 0xffffffffu) {
+        uint32_t why = 0;
+        HIP_TRY(hipMemcpy(&why, d_status.p + first_bad, 4, hipMemcpyDeviceToHost));
+        return fail(IRF_E_PARSE, why == dev::BGZF_BAD_CRC ? "BGZF: CRC mismatch" : "BGZF: inflate failed");
+    }
+
+    // ---- record chain ----
+    const uint64_t start = header_skipped ? 0 : header_len;
+    header_skipped = true;
+    const int32_t n_ref = (int32_t)chr_names.size();
+    uint32_t n_rec = 0;
+    uint64_t tail_off = start;
+    if (total < start) return fail(IRF_E_PARSE, "BAM: truncated header");
+    const uint64_t n_seg64 = (total - start + dev::kChainSegment - 1) / dev::kChainSegment;
+    if (n_seg64 >= 0xffffffffull) return fail(IRF_E_RANGE, "feed too large for one pass: feed the file in pieces");
+    const uint32_t n_seg = (uint32_t)n_seg64;
+    dev::ChainBufs C;
+    memset(&C, 0, sizeof C);
+    if (n_seg) {
+        MEM_TRY(d_guess.reserve(n_seg));
+        MEM_TRY(d_exit.reserve(n_seg));
+        MEM_TRY(d_count.reserve((size_t)n_seg + 4));
+        MEM_TRY(d_seg_base.reserve((size_t)n_seg + 4));
+        MEM_TRY(d_ws.reserve(dev::scan_workspace_elems((uint64_t)n_seg + 1)));
+        C.buf = raw; C.start = start; C.total = total; C.n_seg = n_seg; C.n_ref = n_ref;
+        C.guess = d_guess.p; C.exit_ = d_exit.p; C.count = d_count.p; C.changed = f_changed;
+        HIP_TRY(hipMemsetAsync(d_count.p + n_seg, 0, 4, stream));
+        dev::launch_chain_guess(C, stream);
+        for (uint64_t round = 0;; round++) {
+            uint32_t changed = 0;
+            HIP_TRY(hipMemsetAsync(f_changed, 0, 4, stream));
+            dev::launch_chain_verify(C, stream);
+            HIP_TRY(hipMemcpyAsync(&changed, f_changed, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (!changed) break;
+            if (round > (uint64_t)n_seg + 2) return fail(IRF_E_DEVICE, "record chain did not settle (internal error)");
+        }
+        dev::launch_exclusive_scan_u32(d_count.p, d_seg_base.p, (uint64_t)n_seg + 1, d_ws.p, stream);
+        HIP_TRY(hipMemcpyAsync(&n_rec, d_seg_base.p + n_seg, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&tail_off, d_exit.p + (n_seg - 1), 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    HIP_TRY(hipEventRecord(ev[4], stream));
+
+    // ---- records -> fragments ----
+    OutSlot& O = out[out_cur ^ 1];
+    uint32_t n_frag = 0, n_blk = 0, dangling = 0;
+    unsigned long long scal[1 + dev::RS_COUNT];
+    memset(scal, 0, sizeof scal);
+    scal[0] = ~0ull;
+    HIP_TRY(hipMemcpyAsync(d_scal.p, scal, sizeof scal, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(f_dangling, 0, 4, stream));
+    dev::AssembleArgs A;
+    memset(&A, 0, sizeof A);
+    if (n_rec) {
+        MEM_TRY(d_rec_off.reserve(n_rec));
+        MEM_TRY(d_rec_nf.reserve(n_rec));
+        MEM_TRY(d_fr.reserve((size_t)n_rec + 4));
+        MEM_TRY(d_bl.reserve((size_t)n_rec + 4));
+        MEM_TRY(d_tile_last.reserve(dev::pair_tiles(n_rec)));
+        MEM_TRY(d_tile_carry.reserve(dev::pair_tiles(n_rec)));
+        MEM_TRY(d_ws.reserve(dev::scan_workspace_elems((uint64_t)n_rec + 1)));
+        dev::RecordIndex R{d_rec_off.p, d_rec_nf.p, d_scal.p};
+        dev::launch_chain_emit(C, d_seg_base.p, R, stream);
+        dev::launch_pair_state(d_rec_nf.p, n_rec, d_tile_last.p, d_tile_carry.p, stream);
+        A.buf = raw; A.n_rec = n_rec; A.n_ref = n_ref; A.R = R; A.tile_carry = d_tile_carry.p;
+        A.skip_flag_mask = P.skip_flag_mask; A.pair_long_inclusive = P.pair_long_inclusive; A.pair_short_inclusive = P.pair_short_inclusive;
+        A.fr_cnt = d_fr.p; A.bl_cnt = d_bl.p; A.stats = d_scal.p + 1; A.dangling = f_dangling;
+        HIP_TRY(hipMemsetAsync(d_fr.p + n_rec, 0, 4, stream));
+        HIP_TRY(hipMemsetAsync(d_bl.p + n_rec, 0, 4, stream));
+        dev::launch_assemble_count(A, stream);
+        dev::launch_exclusive_scan_u32(d_fr.p, d_fr.p, (uint64_t)n_rec + 1, d_ws.p, stream);
+        dev::launch_exclusive_scan_u32(d_bl.p, d_bl.p, (uint64_t)n_rec + 1, d_ws.p, stream);
+        HIP_TRY(hipMemcpyAsync(&n_frag, d_fr.p + n_rec, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&n_blk, d_bl.p + n_rec, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&dangling, f_dangling, 4, hipMemcpyDeviceToHost, stream));
+    } else if (n_seg) {
+        // no complete record: a broken chain in the first segment still has to be reported
+        dev::RecordIndex R{nullptr, nullptr, d_scal.p};
+        dev::launch_chain_emit(C, d_seg_base.p, R, stream);
+    }
+    HIP_TRY(hipMemcpyAsync(scal, d_scal.p, sizeof scal, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (scal[0] != ~0ull) return fail(IRF_E_PARSE, (scal[0] & 3ull) == 1ull ? "BAM: bad block_size" : "BAM: record fields overrun block_size");
+    if (tail_off == dev::kNoRecord) return fail(IRF_E_DEVICE, "record chain broken without a bad record (internal error)");
+
+    MEM_TRY(O.frag_chr.reserve(n_frag + 4)); MEM_TRY(O.frag_flags.reserve(n_frag + 4)); MEM_TRY(O.frag_start.reserve(n_frag + 4));
+    MEM_TRY(O.frag_end.reserve(n_frag + 4)); MEM_TRY(O.frag_blk_off.reserve((size_t)n_frag + 5));
+    MEM_TRY(O.blk_start.reserve(n_blk + 4)); MEM_TRY(O.blk_len.reserve(n_blk + 4)); MEM_TRY(O.blk_read.reserve(n_blk + 4));
+    A.frag_chr = O.frag_chr.p; A.frag_flags = O.frag_flags.p; A.frag_start = O.frag_start.p; A.frag_end = O.frag_end.p;
+    A.frag_blk_off = O.frag_blk_off.p; A.blk_start = O.blk_start.p; A.blk_len = O.blk_len.p; A.blk_read = O.blk_read.p;
+    dev::launch_assemble_write(A, n_frag, n_blk, stream);
+    HIP_TRY(hipEventRecord(ev[5], stream));
+    O.n_frag = n_frag; O.n_blk = n_blk;
+
+    // ---- carry: everything behind the last complete unit ----
+    uint64_t tail_from = tail_off;
+    if (dangling) HIP_TRY(hipMemcpyAsync(&tail_from, d_rec_off.p + (n_rec - 1), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t new_carry = total - tail_from;
+    if (new_carry) {
+        MEM_TRY(d_raw[cur ^ 1].reserve(new_carry + 64));
+        HIP_TRY(hipMemcpyAsync(d_raw[cur ^ 1].p, raw + tail_from, new_carry, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    cur ^= 1;
+    carry_len = new_carry;
+    carry_dangling = dangling != 0;
+    carry_partial = tail_off != total;
+    out_cur ^= 1;
+    pending.erase(pending.begin(), pending.begin() + (ptrdiff_t)consumed_in);
+
+    stats.n_records += scal[1 + dev::RS_RECORDS]; stats.n_nucleotides += scal[1 + dev::RS_NUCLEOTIDES];
+    stats.n_singles += scal[1 + dev::RS_SINGLES]; stats.n_pairs += scal[1 + dev::RS_PAIRS];
+    stats.n_pairs_short += scal[1 + dev::RS_SHORT]; stats.n_pairs_intersect += scal[1 + dev::RS_INTERSECT];
+    stats.n_pairs_long += scal[1 + dev::RS_LONG]; stats.n_skipped += scal[1 + dev::RS_SKIPPED]; stats.n_error += scal[1 + dev::RS_ERROR];
+
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); timing.h2d_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); timing.inflate_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); timing.crc_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); timing.chain_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); timing.assemble_ms += ms;
+    timing.bytes_in += consumed_in;
+    timing.bytes_inflated += total_out;
+    timing.n_members += n_members;
+    return 0;
+}
+
+int irf_dreader::finish() {
+    if (failed) return IRF_E_PARSE;
+    if (!pending.empty()) return fail(IRF_E_PARSE, "BGZF: truncated block at end of input");
+    if (!header_done) return fail(IRF_E_PARSE, "BAM: truncated header");
+    if (carry_partial) return fail(IRF_E_PARSE, "BAM: truncated record at end of input");
+    if (carry_dangling) {
+        // the first mate is a record like any other: count it, and the read as an error (as the host reader does)
+        int32_t l_seq = 0;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemcpy(&l_seq, d_raw[cur].p + 20, 4, hipMemcpyDeviceToHost));
+        stats.n_records++;
+        if (l_seq > 0) stats.n_nucleotides += (uint64_t)l_seq;
+        stats.n_error++;
+        carry_dangling = false;
+        carry_len = 0;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int irf_dreader_create(const irf_params* params, int device, irf_dreader** out) {
+    if (!out) return IRF_E_ARG;
+    irf_params P;
+    if (params) {
+        if (params->struct_size != sizeof(irf_params)) return IRF_E_ARG;
+        P = *params;
+    } else {
+        irf_params_default(&P);
+    }
+    if (P.mate_join) return IRF_E_ARG;      // name join of coordinate-sorted input: host reader only (for now)
+    irf_dreader* r = new (std::nothrow) irf_dreader();
+    if (!r) return IRF_E_NOMEM;
+    r->P = P;
+    r->device = device;
+    int rc = r->init();
+    if (rc != 0) { delete r; return rc; }
+    *out = r;
+    return 0;
+}
+
+void irf_dreader_destroy(irf_dreader* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
+    delete r;
+}
+
+const char* irf_dreader_last_error(const irf_dreader* r) { return r ? r->err.c_str() : "null reader"; }
+
+int irf_dreader_feed(irf_dreader* r, const uint8_t* bgzf, size_t len) {
+    if (!r || (!bgzf && len)) return IRF_E_ARG;
+    return r->feed(bgzf, len);
+}
+
+int irf_dreader_header(const irf_dreader* r, const char* const** names, const uint32_t** lens) {
+    if (!r) return IRF_E_ARG;
+    if (!r->header_done) return IRF_E_STATE;
+    if (names) *names = r->chr_name_ptrs.data();
+    if (lens) *lens = r->chr_lens.data();
+    return (int)r->chr_names.size();
+}
+
+int irf_dreader_batch(const irf_dreader* r, irf_batch* out) {
+    if (!r || !out) return IRF_E_ARG;
+    const OutSlot& O = r->out[r->out_cur];
+    memset(out, 0, sizeof *out);
+    out->n_frag = O.n_frag; out->n_blk = O.n_blk;
+    out->frag_chr = O.frag_chr.p; out->frag_flags = O.frag_flags.p; out->frag_start = O.frag_start.p; out->frag_end = O.frag_end.p;
+    out->frag_blk_off = O.frag_blk_off.p; out->blk_start = O.blk_start.p; out->blk_len = O.blk_len.p; out->blk_read = O.blk_read.p;
+    out->mem_kind = IRF_MEM_DEVICE;
+    return 0;
+}
+
+int irf_dreader_finish(irf_dreader* r) { return r ? r->finish() : IRF_E_ARG; }
+
+int irf_dreader_get_stats(const irf_dreader* r, irf_reader_stats* out) {
+    if (!r || !out) return IRF_E_ARG;
+    *out = r->stats;
+    return 0;
+}
+
+int irf_dreader_get_timing(const irf_dreader* r, irf_dreader_timing* out) {
+    if (!r || !out) return IRF_E_ARG;
+    *out = r->timing;
+    return 0;
+}
+
+int irf_copy_to_host(void* dst_host, const void* src_device, size_t bytes) {
+    if (!bytes) return 0;
+    if (!dst_host || !src_device) return IRF_E_ARG;
+    return hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : IRF_E_DEVICE;
+}
+
+int irf_gpu_bgzf_inflate(int device, const uint8_t* bgzf, size_t len, uint8_t* out, size_t out_cap, size_t* out_len) {
+    if ((!bgzf && len) || !out_len) return IRF_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return IRF_E_DEVICE;
+    std::vector<irf::ZBlock> zb;
+    size_t scan = 0, total_out = 0;
+    const std::string e = irf::bgzf_locate(bgzf, len, scan, total_out, zb);
+    if (!e.empty() || scan != len) return IRF_E_PARSE;
+    *out_len = total_out;
+    if (total_out > out_cap) return IRF_E_RANGE;
+    if (total_out == 0) return 0;          // no members, or only empty ones (the EOF marker)
+    if (!out) return IRF_E_ARG;
+    std::vector<dev::BgzfMember> mem(zb.size());
+    for (size_t i = 0; i < zb.size(); i++) mem[i] = dev::BgzfMember{zb[i].in_off, zb[i].out_off, (uint32_t)zb[i].clen, zb[i].isize, zb[i].crc, 0};
+    DBuf<uint8_t> d_in, d_out;
+    DBuf<dev::BgzfMember> d_mem;
+    DBuf<uint32_t> d_status;
+    if (d_in.reserve(len + dev::kInflateSlack) != hipSuccess || d_out.reserve(total_out + 64) != hipSuccess ||
+        d_mem.reserve(mem.size()) != hipSuccess || d_status.reserve(mem.size() + 1) != hipSuccess)
+        return IRF_E_NOMEM;
+    const uint32_t n = (uint32_t)mem.size();
+    bool ok = hipMemcpy(d_in.p, bgzf, len, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(d_in.p + len, 0, dev::kInflateSlack) == hipSuccess;
+    ok = ok && hipMemcpy(d_mem.p, mem.data(), sizeof(dev::BgzfMember) * n, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(d_status.p + n, 0xff, 4) == hipSuccess;
+    if (!ok) return IRF_E_DEVICE;
+    dev::launch_bgzf_inflate(d_in.p, d_mem.p, n, d_out.p, d_status.p, nullptr);
+    dev::launch_bgzf_crc(d_out.p, d_mem.p, n, d_status.p, nullptr);
+    dev::launch_first_bad(d_status.p, n, d_status.p + n, nullptr);
+    uint32_t first_bad = 0;
+    if (hipMemcpy(&first_bad, d_status.p + n, 4, hipMemcpyDeviceToHost) != hipSuccess) return IRF_E_DEVICE;
+    if (first_bad != 0xffffffffu) return IRF_E_PARSE;
+    if (hipMemcpy(out, d_out.p, total_out, hipMemcpyDeviceToHost) != hipSuccess) return IRF_E_DEVICE;
+    return 0;
+}
+
+}   // extern "C"

@@ -1089,6 +1089,11 @@ int irf_chr_map_update(irf_ctx* c, uint32_t n_chr, const char* const* names, con
 
 int irf_submit_batch(irf_ctx* c, const irf_batch* b, uint64_t* id) { return c ? c->submit(b, id) : IRF_E_ARG; }
 int irf_wait(irf_ctx* c, uint64_t id) { return c ? c->wait(id) : IRF_E_ARG; }
+int irf_sync(irf_ctx* c) {
+    if (!c) return IRF_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "irf_sync: stream synchronize failed");
+    return 0;
+}
 int irf_finalize(irf_ctx* c) { return c ? c->finalize() : IRF_E_ARG; }
 int irf_finalize_directional(irf_ctx* c, int32_t d) { return c ? c->finalize_directional(d) : IRF_E_ARG; }
 int irf_get_votes(irf_ctx* c, uint64_t out[2]) {

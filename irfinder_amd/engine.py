@@ -9,8 +9,8 @@ import os
 
 import numpy as np
 
-from ._abi import (STATUS, Batch, IrfBatch, IrfLayout, IrfParams, IrfReaderStats, IrfResults, IrfTiming, IRF_MEM_DEVICE,
-                   IRF_MEM_HOST, results_to_dict)
+from ._abi import (STATUS, Batch, IrfBatch, IrfDreaderTiming, IrfLayout, IrfParams, IrfReaderStats, IrfResults, IrfTiming,
+                   IRF_MEM_DEVICE, IRF_MEM_HOST, results_to_dict)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRF_LIB_PATH") or os.path.join(_HERE, "libirfhip.so")   # IRF_LIB_PATH: kernel-tuning builds only
@@ -97,6 +97,20 @@ def lib():
     L.irf_reader_finish.argtypes = [vp]
     L.irf_reader_get_stats.argtypes = [vp, C.POINTER(IrfReaderStats)]
     L.irf_cigar2block.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.irf_sync.argtypes = [vp]
+    L.irf_dreader_create.argtypes = [C.POINTER(IrfParams), C.c_int, C.POINTER(vp)]
+    L.irf_dreader_destroy.argtypes = [vp]
+    L.irf_dreader_destroy.restype = None
+    L.irf_dreader_last_error.argtypes = [vp]
+    L.irf_dreader_last_error.restype = C.c_char_p
+    L.irf_dreader_feed.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.irf_dreader_header.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(u32))]
+    L.irf_dreader_batch.argtypes = [vp, C.POINTER(IrfBatch)]
+    L.irf_dreader_finish.argtypes = [vp]
+    L.irf_dreader_get_stats.argtypes = [vp, C.POINTER(IrfReaderStats)]
+    L.irf_dreader_get_timing.argtypes = [vp, C.POINTER(IrfDreaderTiming)]
+    L.irf_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.irf_gpu_bgzf_inflate.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _LIB = L
     return L
 
@@ -231,6 +245,106 @@ class Reader:
             pass
 
 
+def _buf(data):
+    """(pointer, byte count, keep-alive object) of bytes-like input."""
+    if isinstance(data, np.ndarray):
+        a = np.ascontiguousarray(data)
+        return a.ctypes.data, a.nbytes, a
+    data = bytes(data)
+    return C.cast(C.c_char_p(data), C.c_void_p), len(data), data
+
+
+def gpu_bgzf_inflate(data, device=0):
+    """Whole BGZF members -> inflated bytes, inflated and CRC-checked on the device (irf_gpu_bgzf_inflate)."""
+    L = lib()
+    ptr, n, keep = _buf(data)
+    need = C.c_size_t()
+    rc = L.irf_gpu_bgzf_inflate(int(device), ptr, n, None, 0, C.byref(need))
+    if rc not in (0, -3):
+        raise IrfError(rc, "irf_gpu_bgzf_inflate")
+    out = np.empty(need.value, np.uint8)
+    if need.value:
+        rc = L.irf_gpu_bgzf_inflate(int(device), ptr, n, out.ctypes.data, out.nbytes, C.byref(need))
+        if rc != 0:
+            raise IrfError(rc, "irf_gpu_bgzf_inflate")
+    return out
+
+
+class DeviceReader:
+    """Device reader (irf_dreader_*): compressed BGZF bytes in, DEVICE-resident fragment batches out."""
+
+    def __init__(self, params=None, device=0):
+        self.L = lib()
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        rc = self.L.irf_dreader_create(C.byref(self.params), int(device), C.byref(self.h))
+        if rc != 0:
+            raise IrfError(rc, "irf_dreader_create failed (no HIP device, or params.mate_join set)")
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise IrfError(rc, self.L.irf_dreader_last_error(self.h).decode())
+
+    def feed(self, data):
+        ptr, n, keep = _buf(data)
+        self._chk(self.L.irf_dreader_feed(self.h, ptr, n))
+
+    def finish(self):
+        self._chk(self.L.irf_dreader_finish(self.h))
+
+    def header(self):
+        names = C.POINTER(C.c_char_p)()
+        lens = C.POINTER(C.c_uint32)()
+        n = self.L.irf_dreader_header(self.h, C.byref(names), C.byref(lens))
+        if n < 0:
+            raise IrfError(n, "BAM header not complete")
+        return [names[i].decode() for i in range(n)], [int(lens[i]) for i in range(n)]
+
+    def batch_struct(self):
+        """irf_batch (device pointers) of the last feed; valid until the next-but-one feed."""
+        b = IrfBatch()
+        self._chk(self.L.irf_dreader_batch(self.h, C.byref(b)))
+        return b
+
+    def batch_to_host(self):
+        """Copy of the last feed's fragments in host memory (tests)."""
+        b = self.batch_struct()
+        arrays = {}
+        for name, dt in Batch.FIELDS:
+            n = b.n_blk if name.startswith("blk_") else b.n_frag + (1 if name == "frag_blk_off" else 0)
+            a = np.zeros(n, dt)
+            if name == "frag_blk_off" and b.n_frag == 0:
+                arrays[name] = a
+                continue
+            if a.nbytes:
+                rc = self.L.irf_copy_to_host(a.ctypes.data, getattr(b, name), a.nbytes)
+                if rc != 0:
+                    raise IrfError(rc, "irf_copy_to_host")
+            arrays[name] = a
+        return Batch(**arrays)
+
+    def stats(self):
+        rs = IrfReaderStats()
+        self._chk(self.L.irf_dreader_get_stats(self.h, C.byref(rs)))
+        return {n: int(getattr(rs, n)) for n, _ in IrfReaderStats._fields_}
+
+    def timing(self):
+        t = IrfDreaderTiming()
+        self._chk(self.L.irf_dreader_get_timing(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in IrfDreaderTiming._fields_ if n != "reserved"}
+
+    def close(self):
+        if self.h:
+            self.L.irf_dreader_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One irf_ctx: mirrors ReadBlockProcessor's ChrMapUpdate / ProcessBlocks (batched) + the end-of-run writers."""
 
@@ -270,6 +384,9 @@ class Engine:
     def process(self, batch):
         bid = self.submit(batch)
         self.wait(bid)
+
+    def sync(self):
+        self._chk(self.L.irf_sync(self.h))
 
     def finalize(self):
         self._chk(self.L.irf_finalize(self.h))

@@ -130,15 +130,12 @@ int BamReader::feed(const uint8_t* data, size_t len, bool bgzf) {
 // BGZF (SAM spec §4.1): gzip members with a 'BC' extra subfield carrying BSIZE.  The complete members in the buffer are
 // located first (their inflated sizes are in the trailers, so every member knows where its output goes), then
 // inflated and CRC-checked independently — by the worker pool when there is one.
-int BamReader::inflate_blocks() {
-    zblocks_.clear();
-    size_t scan = zoff_, total_out = 0;
-    std::string scan_error;
+std::string bgzf_locate(const uint8_t* buf, size_t size, size_t& scan, size_t& total_out, std::vector<ZBlock>& out) {
     while (true) {
-        size_t avail = zbuf_.size() - scan;
+        size_t avail = size - scan;
         if (avail < 18) break;
-        const uint8_t* h = zbuf_.data() + scan;
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { scan_error = "BGZF: bad member header"; break; }
+        const uint8_t* h = buf + scan;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return "BGZF: bad member header";
         uint32_t xlen = le16(h + 10);
         if (avail < 12 + (size_t)xlen) break;
         uint32_t bsize = 0;
@@ -149,21 +146,28 @@ int BamReader::inflate_blocks() {
             if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = le16(sf + 4); found = true; }
             x += 4 + slen;
         }
-        if (!found) { scan_error = "BGZF: missing BC subfield"; break; }
+        if (!found) return "BGZF: missing BC subfield";
         size_t total = (size_t)bsize + 1;
-        if (total < 12 + (size_t)xlen + 8) { scan_error = "BGZF: bad BSIZE"; break; }
+        if (total < 12 + (size_t)xlen + 8) return "BGZF: bad BSIZE";
         if (avail < total) break;
         ZBlock b;
         b.in_off = scan + 12 + xlen;
         b.clen = total - 12 - xlen - 8;
         b.crc = le32(h + total - 8);
         b.isize = le32(h + total - 4);
-        if (b.isize > 65536) { scan_error = "BGZF: ISIZE > 64 KiB"; break; }
+        if (b.isize > 65536) return "BGZF: ISIZE > 64 KiB";
         b.out_off = total_out;
         total_out += b.isize;
-        zblocks_.push_back(b);
+        out.push_back(b);
         scan += total;
     }
+    return std::string();
+}
+
+int BamReader::inflate_blocks() {
+    zblocks_.clear();
+    size_t scan = zoff_, total_out = 0;
+    const std::string scan_error = bgzf_locate(zbuf_.data(), zbuf_.size(), scan, total_out, zblocks_);
     // (the members before a malformed one are still inflated, as when reading them one by one; the error is sticky)
     if (roff_ > (1u << 20) && roff_ * 2 > raw_.size()) { raw_.erase(raw_.begin(), raw_.begin() + (ptrdiff_t)roff_); roff_ = 0; }
     const size_t at = raw_.size();
@@ -222,37 +226,46 @@ int BamReader::inflate_blocks() {
 }
 
 // ⟨upstream⟩ BAM2blocks::readBamHeader
-int BamReader::parse_header(bool& need_more, size_t limit) {
-    need_more = true;
-    const uint8_t* p = raw_.data() + roff_;
-    size_t avail = limit - roff_, o = 0;
-    if (avail < 12) return 0;
+int parse_bam_header(const uint8_t* p, size_t avail, std::vector<std::string>& names_out, std::vector<uint32_t>& lens_out,
+                     size_t& consumed, std::string& error) {
+    size_t o = 0;
+    if (avail < 12) return 1;
     if (memcmp(p, "BAM\1", 4) != 0) { error = "BAM: bad magic"; return IRF_E_PARSE; }
     int32_t l_text = (int32_t)le32(p + 4);
     if (l_text < 0) { error = "BAM: negative l_text"; return IRF_E_PARSE; }
     o = 8 + (size_t)l_text;
-    if (avail < o + 4) return 0;
+    if (avail < o + 4) return 1;
     int32_t n_ref = (int32_t)le32(p + o);
     if (n_ref < 0) { error = "BAM: negative n_ref"; return IRF_E_PARSE; }
     o += 4;
     std::vector<std::string> names;
     std::vector<uint32_t> lens;
     for (int32_t i = 0; i < n_ref; i++) {
-        if (avail < o + 4) return 0;
+        if (avail < o + 4) return 1;
         int32_t l_name = (int32_t)le32(p + o);
         if (l_name <= 0 || l_name > (1 << 20)) { error = "BAM: bad l_name"; return IRF_E_PARSE; }
         o += 4;
-        if (avail < o + (size_t)l_name + 4) return 0;
+        if (avail < o + (size_t)l_name + 4) return 1;
         names.emplace_back((const char*)p + o, (size_t)l_name - 1);
         o += (size_t)l_name;
         lens.push_back(le32(p + o));
         o += 4;
     }
-    chr_names.swap(names);
-    chr_lens.swap(lens);
+    names_out.swap(names);
+    lens_out.swap(lens);
+    consumed = o;
+    return 0;
+}
+
+int BamReader::parse_header(bool& need_more, size_t limit) {
+    need_more = true;
+    size_t consumed = 0;
+    const int rc = parse_bam_header(raw_.data() + roff_, limit - roff_, chr_names, chr_lens, consumed, error);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
     chr_name_ptrs.clear();
     for (auto& s : chr_names) chr_name_ptrs.push_back(s.c_str());
-    roff_ += o;
+    roff_ += consumed;
     header_done_ = true;
     need_more = false;
     return 0;

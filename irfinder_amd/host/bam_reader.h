@@ -25,6 +25,16 @@ namespace irf {
 // cigar words -> absolute aligned blocks; returns the reference end of the read
 uint32_t cigar_to_blocks(uint32_t pos, const uint32_t* cigar, uint32_t n_cigar, std::vector<BlockSpan>& out);
 
+// One complete BGZF member inside a buffer: where its DEFLATE data is, where its inflated bytes go
+struct ZBlock { size_t in_off, clen, out_off; uint32_t isize, crc; };
+// Locates the complete BGZF members of buf[scan, size): appends them to out (out_off continues from total_out), moves
+// scan behind the last complete member.  Returns the empty string, or what is wrong with the member at scan.
+std::string bgzf_locate(const uint8_t* buf, size_t size, size_t& scan, size_t& total_out, std::vector<ZBlock>& out);
+// ⟨upstream⟩ BAM2blocks::readBamHeader on p[0, avail): 0 = parsed (consumed bytes, names, lens), 1 = needs more bytes,
+// IRF_E_PARSE = malformed (error text set)
+int parse_bam_header(const uint8_t* p, size_t avail, std::vector<std::string>& names, std::vector<uint32_t>& lens,
+                     size_t& consumed, std::string& error);
+
 // A few persistent worker threads that share a loop over item indices (BGZF blocks are independent deflate members:
 // SURVEY §8 f N1).  run() returns when every index has been processed; the caller's thread works too.
 class WorkerPool {
@@ -94,7 +104,6 @@ private:
     // params.mate_join: records whose mate has not been seen yet, by read name (coordinate-sorted input)
     std::unordered_map<std::string, Rec> waiting_;
     std::vector<BlockSpan> b1_, b2_, merged_;
-    struct ZBlock { size_t in_off, clen, out_off; uint32_t isize, crc; };
     std::vector<ZBlock> zblocks_;
     std::vector<void*> zs_;              // one z_stream per worker
     WorkerPool* pool_ = nullptr;

@@ -143,7 +143,7 @@ struct Writer {
 };
 
 void write_record(Writer& w, int32_t ref, const Aln& a, uint16_t flag, int32_t mref, int32_t mpos, uint64_t pair_idx,
-                  bool with_seq) {
+                  uint32_t with_seq) {
     char name[24];
     int ln = snprintf(name, sizeof name, "p%llx", (unsigned long long)pair_idx) + 1;
     int32_t l_seq = with_seq ? (int32_t)a.qlen : 0;
@@ -156,7 +156,25 @@ void write_record(Writer& w, int32_t ref, const Aln& a, uint16_t flag, int32_t m
     w.put(&n_cigar, 2); w.put(&flag, 2); w.put(&l_seq, 4); w.put(&mref, 4); w.put(&mpos, 4); w.put(&tlen, 4);
     w.put(name, (size_t)ln);
     w.put(a.cig, 4 * (size_t)a.ncig);
-    if (l_seq) { w.fill(0x11, (size_t)(l_seq + 1) / 2); w.fill(30, (size_t)l_seq); }
+    if (l_seq && with_seq == 2) {
+        /* random bases (2 bits of entropy per base) and binned qualities: compresses about as a real RNA-seq BAM does */
+        Rng r(0x5eed, pair_idx * 2 + ((flag & 0x80) ? 1 : 0));
+        static const uint8_t nib[4] = {1, 2, 4, 8};
+        static const uint8_t qbin[8] = {37, 37, 37, 37, 37, 23, 12, 2};
+        uint8_t tmp[1024];
+        size_t nb = (size_t)(l_seq + 1) / 2;
+        for (size_t i = 0; i < nb; i += sizeof tmp) {
+            size_t k = nb - i < sizeof tmp ? nb - i : sizeof tmp;
+            for (size_t j = 0; j < k; j++) { uint64_t x = r.next(); tmp[j] = (uint8_t)(nib[x & 3] << 4 | nib[(x >> 2) & 3]); }
+            w.put(tmp, k);
+        }
+        for (size_t i = 0; i < (size_t)l_seq; i += sizeof tmp) {
+            size_t k = (size_t)l_seq - i < sizeof tmp ? (size_t)l_seq - i : sizeof tmp;
+            uint64_t x = 0;
+            for (size_t j = 0; j < k; j++) { if ((j & 15) == 0) x = r.next(); tmp[j] = qbin[x & 7]; x >>= 3; }
+            w.put(tmp, k);
+        }
+    } else if (l_seq) { w.fill(0x11, (size_t)(l_seq + 1) / 2); w.fill(30, (size_t)l_seq); }
 }
 
 int upper_cdf(const double* cdf, int n, double u) {
@@ -226,7 +244,7 @@ size_t synth_bam_records(const synth_model* M, uint64_t first, uint64_t n, uint8
         else left_is_read1 = (r.next() & 1) != 0;
         if (r.uni() < M->single_frac) {
             uint16_t f = (r.next() & 1) ? 0x10 : 0;
-            write_record(w, ref, A, f, -1, -1, i, M->with_seq != 0);
+            write_record(w, ref, A, f, -1, -1, i, M->with_seq);
             nrec += 1;
             continue;
         }
@@ -234,11 +252,11 @@ size_t synth_bam_records(const synth_model* M, uint64_t first, uint64_t n, uint8
         uint16_t fl_right = 0x1 | 0x2 | 0x10 | (left_is_read1 ? 0x80 : 0x40);
         /* stream order: read 1 first */
         if (left_is_read1) {
-            write_record(w, ref, A, fl_left, ref, (int32_t)B.pos, i, M->with_seq != 0);
-            write_record(w, ref, B, fl_right, ref, (int32_t)A.pos, i, M->with_seq != 0);
+            write_record(w, ref, A, fl_left, ref, (int32_t)B.pos, i, M->with_seq);
+            write_record(w, ref, B, fl_right, ref, (int32_t)A.pos, i, M->with_seq);
         } else {
-            write_record(w, ref, B, fl_right, ref, (int32_t)A.pos, i, M->with_seq != 0);
-            write_record(w, ref, A, fl_left, ref, (int32_t)B.pos, i, M->with_seq != 0);
+            write_record(w, ref, B, fl_right, ref, (int32_t)A.pos, i, M->with_seq);
+            write_record(w, ref, A, fl_left, ref, (int32_t)B.pos, i, M->with_seq);
         }
         nrec += 2;
     }

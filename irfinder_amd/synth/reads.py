@@ -84,7 +84,7 @@ class ReadSimulator:
         m.read_len, m.stranded = int(read_len), int(bool(stranded))
         m.frag_mean, m.frag_sd = float(frag_mean), float(frag_sd)
         m.noise_frac, m.indel_frac, m.clip_frac, m.single_frac = noise_frac, indel_frac, clip_frac, single_frac
-        m.seed, m.with_seq = int(seed), int(bool(with_seq))
+        m.seed, m.with_seq = int(seed), int(with_seq)     # 0: no seq/qual, 1: constant bytes, 2: random bases + binned quals
         self.model = m
 
     def header(self):
