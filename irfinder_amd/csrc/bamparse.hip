@@ -104,12 +104,18 @@ __global__ __launch_bounds__(kThreads) void chain_guess_kernel(ChainBufs C) {
 // Every thread re-walks its own segment from the guess it reads (exit_ / count may have been left behind by a walker
 // that lost a race), so after a launch the guesses of a prefix one segment longer are final: threads inside the prefix
 // write nothing, walkers only ever write segments ahead of them.  A launch that writes nothing has checked everything.
+// Only a thread whose own guess is what its predecessor arrived at (as of the previous launch) carries its walk on: a
+// wrongly guessed start is a chain through arbitrary bytes, whose "block sizes" would send the walker across thousands
+// of segments, overwriting good guesses on the way.  Segment 0 is always confirmed, and a launch that changes nothing
+// confirms segment i + 1 from segment i, so neither the induction nor the end condition changes.
 __global__ __launch_bounds__(kThreads) void chain_verify_kernel(ChainBufs C) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= C.n_seg) return;
     bool touched = false;
     uint32_t n;
-    uint64_t cur = walk_segment(C.buf, C.guess[i], segment_end(C, i), C.total, &n);
+    const uint64_t g = C.guess[i];
+    const bool confirmed = i == 0 || C.exit_[i - 1] == g;
+    uint64_t cur = walk_segment(C.buf, g, segment_end(C, i), C.total, &n);
     if (C.exit_[i] != cur || C.count[i] != n) {
         C.exit_[i] = cur;
         C.count[i] = n;
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void chain_verify_kernel(ChainBufs C) {
     }
     uint32_t j = i + 1;
     // (a broken chain is not carried on: the break is reported by chain_emit, what follows it is never used)
-    while (j < C.n_seg && cur != kNoRecord && C.guess[j] != cur) {
+    while (confirmed && j < C.n_seg && cur != kNoRecord && C.guess[j] != cur) {
         const uint64_t e = walk_segment(C.buf, cur, segment_end(C, j), C.total, &n);
         C.guess[j] = cur;
         C.exit_[j] = e;

@@ -329,14 +329,58 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             flush();
             uint8_t* dst = obase + op;
             const uint8_t* src = dst - dist;
+            // Whole 8-byte steps may write up to 8 bytes past the end of the match as long as they stay inside the member:
+            // the output that follows overwrites them (a member that ends early is refused: op != isize).
+            const bool may_overrun = op + len + 8u <= isize;
             op += len;
             if (dist >= 8) {
+                if (dist >= 32) {
+                    while (len >= 32) {          // one round trip per 32 bytes
+                        uint32_t w[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) w[k] = ld32u(src + 4 * k);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) st32u(dst + 4 * k, w[k]);
+                        src += 32; dst += 32; len -= 32;
+                    }
+                    if (len > 8 && may_overrun) {    // the rest (< 32 bytes), still one round trip
+                    const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4), w2 = ld32u(src + 8), w3 = ld32u(src + 12);
+                    st32u(dst, w0); st32u(dst + 4, w1);
+                    if (len > 16) {
+                        const uint32_t w4 = ld32u(src + 16), w5 = ld32u(src + 20), w6 = ld32u(src + 24), w7 = ld32u(src + 28);
+                        st32u(dst + 8, w2); st32u(dst + 12, w3); st32u(dst + 16, w4); st32u(dst + 20, w5);
+                        if (len > 24) { st32u(dst + 24, w6); st32u(dst + 28, w7); }
+                    } else {
+                        st32u(dst + 8, w2); st32u(dst + 12, w3);
+                    }
+                    len = 0;
+                    }
+                }
                 while (len >= 8) {
                     const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
                     st32u(dst, w0);
                     st32u(dst + 4, w1);
                     src += 8; dst += 8; len -= 8;
                 }
+                if (len && may_overrun) {
+                    const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
+                    st32u(dst, w0);
+                    st32u(dst + 4, w1);
+                    len = 0;
+                }
+            } else if (may_overrun) {
+                // the match overlaps its own output: a pattern of period dist, built in registers from one load
+                uint64_t pat = (uint64_t)ld32u(src) | (uint64_t)ld32u(src + 4) << 32;
+                pat &= ~0ull >> (64u - 8u * dist);
+                for (uint32_t sh = dist; sh < 8; sh <<= 1) pat |= pat << (8u * sh);
+                const uint32_t step = dist == 3 ? 6u : dist == 5 ? 5u : dist == 6 ? 6u : dist == 7 ? 7u : 8u;   // multiple of dist
+                while (true) {
+                    st32u(dst, (uint32_t)pat);
+                    st32u(dst + 4, (uint32_t)(pat >> 32));
+                    if (len <= step) break;
+                    dst += step; len -= step;
+                }
+                len = 0;
             }
             if (dist >= 4) {
                 while (len >= 4) {

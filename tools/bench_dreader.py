@@ -1,0 +1,98 @@
+"""Throughput of the device reader (irf_dreader_*) on a synthetic BGZF BAM with sequence + quality bytes, next to the host
+reader on the same bytes.  One JSON line.  python tools/bench_dreader.py [--pairs N] [--level L] [--piece MB]"""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+from multiprocessing import Pool
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+
+from irfinder_amd import engine
+from irfinder_amd.synth.annotation import make_annotation, small_chroms
+from irfinder_amd.synth.bam import BGZF_EOF, bgzf_compress
+from irfinder_amd.synth.reads import ReadSimulator
+
+LEVEL = 6
+
+
+def _comp(chunk):
+    return bgzf_compress(chunk, level=LEVEL)[:-len(BGZF_EOF)]
+
+
+def make_bgzf(raw, level, workers=16):
+    global LEVEL
+    LEVEL = level
+    step = 0xff00 * 64
+    with Pool(workers, initializer=_set_level, initargs=(level,)) as p:
+        parts = p.map(_comp, [raw[i:i + step] for i in range(0, len(raw), step)])
+    return b"".join(parts) + BGZF_EOF
+
+
+def _set_level(level):
+    global LEVEL
+    LEVEL = level
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1_000_000)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--piece", type=int, default=0, help="feed size in MB of compressed bytes (0: the whole file at once)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--host-threads", type=int, default=16)
+    args = ap.parse_args()
+    ann = make_annotation(small_chroms(4, 20_000_000), seed=9)
+    sim = ReadSimulator(ann, read_len=args.read_len, seed=9, with_seq=2)
+    t0 = time.perf_counter()
+    raw = sim.bam(0, args.pairs)
+    z = make_bgzf(raw, args.level)
+    print("[bench_dreader] %d pairs, %.1f MB BAM, %.1f MB BGZF (level %d), made in %.1fs" % (
+        args.pairs, len(raw) / 1e6, len(z) / 1e6, args.level, time.perf_counter() - t0), file=sys.stderr, flush=True)
+    zb = np.frombuffer(z, np.uint8)
+    piece = args.piece << 20 if args.piece else len(z)
+    out = {"pairs": args.pairs, "bam_MB": round(len(raw) / 1e6, 1), "bgzf_MB": round(len(z) / 1e6, 1), "level": args.level,
+           "piece_MB": args.piece or round(len(z) / 1e6, 1)}
+    best = None
+    for rep in range(args.reps):
+        d = engine.DeviceReader()
+        t0 = time.perf_counter()
+        n_frag = 0
+        for i in range(0, len(z), piece):
+            d.feed(zb[i:i + piece])
+            n_frag += d.batch_struct().n_frag
+        d.finish()
+        dt = time.perf_counter() - t0
+        t = d.timing()
+        st = d.stats()
+        d.close()
+        if best is None or dt < best[0]:
+            best = (dt, t, n_frag, st)
+    dt, t, n_frag, st = best
+    kern = t["inflate_ms"] + t["crc_ms"] + t["chain_ms"] + t["assemble_ms"]
+    out["device"] = {"wall_s": round(dt, 4), "pairs_per_s_wall": round(args.pairs / dt, 1), "bgzf_MBps_wall": round(len(z) / dt / 1e6, 1),
+                     "bam_GBps_wall": round(len(raw) / dt / 1e9, 2),
+                     "device_ms": {k: round(v, 3) for k, v in t.items() if k.endswith("_ms")},
+                     "pairs_per_s_device_stages": round(args.pairs / (kern / 1e3), 1),
+                     "bam_GBps_device_stages": round(len(raw) / (kern / 1e3) / 1e9, 2),
+                     "inflate_GBps_out": round(len(raw) / (t["inflate_ms"] / 1e3) / 1e9, 2), "n_frag": n_frag, "n_members": t["n_members"]}
+    r = engine.Reader(threads=args.host_threads)
+    t0 = time.perf_counter()
+    for i in range(0, len(z), 16 << 20):
+        r.feed(zb[i:i + (16 << 20)], bgzf=True)
+    r.finish()
+    dth = time.perf_counter() - t0
+    hs = r.stats()
+    out["host"] = {"threads": args.host_threads, "wall_s": round(dth, 4), "pairs_per_s": round(args.pairs / dth, 1),
+                   "bam_GBps": round(len(raw) / dth / 1e9, 2)}
+    out["same_counters"] = hs == st
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
