@@ -42,6 +42,65 @@ struct DBuf {
     }
 };
 
+// The compressed input of a feed: what the previous feeds left over (a partial member), then the caller's bytes —
+// never copied into one host buffer; only what a feed leaves unconsumed is kept.
+struct TwoSpan {
+    const uint8_t* a; size_t na;
+    const uint8_t* b; size_t nb;
+    size_t size() const { return na + nb; }
+    // [off, off + n) as contiguous bytes: inside a, inside b, or copied into tmp where it straddles the seam
+    const uint8_t* view(size_t off, size_t n, std::vector<uint8_t>& tmp) const {
+        if (off + n <= na) return a + off;
+        if (off >= na) return b + (off - na);
+        tmp.resize(n);
+        memcpy(tmp.data(), a + off, na - off);
+        memcpy(tmp.data() + (na - off), b, n - (na - off));
+        return tmp.data();
+    }
+};
+
+inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+inline uint32_t rd32(const uint8_t* p) { return rd16(p) | rd16(p + 2) << 16; }
+
+// host/bam_reader.cpp: bgzf_locate, over a TwoSpan (same checks, same messages)
+std::string locate_members(const TwoSpan& in, size_t& scan, size_t& total_out, std::vector<irf::ZBlock>& out) {
+    std::vector<uint8_t> tmp;
+    const size_t size = in.size();
+    while (true) {
+        const size_t avail = size - scan;
+        if (avail < 18) break;
+        const uint8_t* h = in.view(scan, 12, tmp);
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return "BGZF: bad member header";
+        const uint32_t xlen = rd16(h + 10);
+        if (avail < 12 + (size_t)xlen) break;
+        const uint8_t* x0 = in.view(scan + 12, xlen, tmp);
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t* sf = x0 + x;
+            const uint32_t slen = rd16(sf + 2);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = rd16(sf + 4); found = true; }
+            x += 4 + slen;
+        }
+        if (!found) return "BGZF: missing BC subfield";
+        const size_t total = (size_t)bsize + 1;
+        if (total < 12 + (size_t)xlen + 8) return "BGZF: bad BSIZE";
+        if (avail < total) break;
+        const uint8_t* t = in.view(scan + total - 8, 8, tmp);
+        irf::ZBlock b;
+        b.in_off = scan + 12 + xlen;
+        b.clen = total - 12 - xlen - 8;
+        b.crc = rd32(t);
+        b.isize = rd32(t + 4);
+        if (b.isize > 65536) return "BGZF: ISIZE > 64 KiB";
+        b.out_off = total_out;
+        total_out += b.isize;
+        out.push_back(b);
+        scan += total;
+    }
+    return std::string();
+}
+
 struct OutSlot {
     DBuf<uint32_t> frag_chr, frag_start, frag_end, frag_blk_off, blk_start, blk_len;
     DBuf<uint8_t> frag_flags, blk_read;
@@ -88,9 +147,9 @@ struct irf_dreader {
     int fail(int code, const std::string& msg) { err = msg; failed = true; return code; }
     int init();
     int feed(const uint8_t* data, size_t len);
-    int process(size_t consumed_in);
+    int process(const TwoSpan& in, size_t consumed_in);
     int finish();
-    int host_header(size_t n_members_avail);
+    int host_header(const TwoSpan& in, size_t n_members_avail);
 };
 
 #define HIP_TRY(expr)                                                                            \
@@ -118,8 +177,8 @@ int irf_dreader::init() {
 // The BAM header is needed on the host (irf_chr_map_update wants names and lengths before any batch): the leading
 // members are inflated with zlib until it is complete.  The device inflates them again with the rest and starts at
 // header_len.
-int irf_dreader::host_header(size_t n_avail) {
-    std::vector<uint8_t> raw;
+int irf_dreader::host_header(const TwoSpan& in, size_t n_avail) {
+    std::vector<uint8_t> raw, tmp;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return fail(IRF_E_NOMEM, "zlib: inflateInit2 failed");
@@ -130,7 +189,7 @@ int irf_dreader::host_header(size_t n_avail) {
             const size_t at = raw.size();
             raw.resize(at + b.isize);
             inflateReset(&zs);
-            zs.next_in = const_cast<Bytef*>(pending.data() + b.in_off);
+            zs.next_in = const_cast<Bytef*>(in.view(b.in_off, b.clen, tmp));
             zs.avail_in = (uInt)b.clen;
             zs.next_out = raw.data() + at;
             zs.avail_out = b.isize;
@@ -155,22 +214,36 @@ int irf_dreader::host_header(size_t n_avail) {
 int irf_dreader::feed(const uint8_t* data, size_t len) {
     if (failed) return IRF_E_PARSE;
     HIP_TRY(hipSetDevice(device));
-    pending.insert(pending.end(), data, data + len);
+    const TwoSpan in{pending.data(), pending.size(), data, len};
     zblocks.clear();
     size_t scan = 0, total_out = 0;
-    const std::string scan_error = irf::bgzf_locate(pending.data(), pending.size(), scan, total_out, zblocks);
+    const std::string scan_error = locate_members(in, scan, total_out, zblocks);
     if (!scan_error.empty()) return fail(IRF_E_PARSE, scan_error);
     out[out_cur ^ 1].n_frag = out[out_cur ^ 1].n_blk = 0;
-    if (zblocks.empty()) { out_cur ^= 1; return 0; }
-    if (!header_done) {
-        int rc = host_header(zblocks.size());
+    bool consume = !zblocks.empty();
+    if (consume && !header_done) {
+        int rc = host_header(in, zblocks.size());
         if (rc != 0) return rc;
-        if (!header_done) { out_cur ^= 1; return 0; }    // wait for more members (nothing consumed)
+        consume = header_done;                            // else: wait for more members (nothing consumed)
     }
-    return process(scan);
+    if (!consume) {
+        pending.insert(pending.end(), data, data + len);
+        out_cur ^= 1;
+        return 0;
+    }
+    int rc = process(in, scan);
+    if (rc != 0) return rc;
+    // what is left behind the last complete member
+    if (scan >= in.na) {
+        pending.assign(data + (scan - in.na), data + len);
+    } else {
+        pending.erase(pending.begin(), pending.begin() + (ptrdiff_t)scan);
+        pending.insert(pending.end(), data, data + len);
+    }
+    return 0;
 }
 
-int irf_dreader::process(size_t consumed_in) {
+int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
     const uint32_t n_members = (uint32_t)zblocks.size();
     members.resize(n_members);
     uint64_t total_out = 0;
@@ -196,7 +269,11 @@ int irf_dreader::process(size_t consumed_in) {
     uint32_t* const f_changed = d_flags.p, *const f_first_bad = d_flags.p + 1, *const f_dangling = d_flags.p + 2;
 
     HIP_TRY(hipEventRecord(ev[0], stream));
-    HIP_TRY(hipMemcpyAsync(d_in.p, pending.data(), consumed_in, hipMemcpyHostToDevice, stream));
+    {
+        const size_t from_a = std::min(in.na, consumed_in);
+        if (from_a) HIP_TRY(hipMemcpyAsync(d_in.p, in.a, from_a, hipMemcpyHostToDevice, stream));
+        if (consumed_in > from_a) HIP_TRY(hipMemcpyAsync(d_in.p + from_a, in.b, consumed_in - from_a, hipMemcpyHostToDevice, stream));
+    }
     HIP_TRY(hipMemsetAsync(d_in.p + consumed_in, 0, dev::kInflateSlack, stream));
     HIP_TRY(hipMemcpyAsync(d_members.p, members.data(), sizeof(dev::BgzfMember) * n_members, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemsetAsync(f_first_bad, 0xff, 4, stream));
@@ -321,7 +398,6 @@ int irf_dreader::process(size_t consumed_in) {
     carry_dangling = dangling != 0;
     carry_partial = tail_off != total;
     out_cur ^= 1;
-    pending.erase(pending.begin(), pending.begin() + (ptrdiff_t)consumed_in);
 
     stats.n_records += scal[1 + dev::RS_RECORDS]; stats.n_nucleotides += scal[1 + dev::RS_NUCLEOTIDES];
     stats.n_singles += scal[1 + dev::RS_SINGLES]; stats.n_pairs += scal[1 + dev::RS_PAIRS];

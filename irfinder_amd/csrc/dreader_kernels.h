@@ -21,7 +21,8 @@ struct BgzfMember {
     uint32_t pad;
 };
 enum BgzfStatus : uint32_t { BGZF_OK = 0, BGZF_BAD_DEFLATE = 1, BGZF_BAD_CRC = 2 };
-constexpr uint32_t kInflateSlack = 16;   // readable bytes the compressed buffer must have behind its last member
+constexpr uint32_t kInflateSlack = 1024; // readable bytes the compressed buffer must have behind its last member (a corrupt
+                                         // dynamic-block header is read to its end, <= 600 bytes, before the input limit is checked)
 
 // status[m] = BGZF_OK / BGZF_BAD_DEFLATE.  `in` must be readable kInflateSlack bytes past the last member.
 void launch_bgzf_inflate(const uint8_t* in, const BgzfMember* members, uint32_t n_members, uint8_t* out, uint32_t* status,

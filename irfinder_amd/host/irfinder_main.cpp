@@ -1,7 +1,7 @@
 // irfinder_main.cpp — command-line drop-in for the upstream engine binary.
 //
 //   irfinder_hip OUTDIR ref-cover.bed ref-sj.ref ref-read-continues.ref ref-ROI.bed [--bgzf] [--device N]
-//                [--via-adapter] [--sorted] [--threads N] < input.bam
+//                [--via-adapter] [--sorted] [--threads N] [--device-reader [--feed-mb N]] < input.bam
 //
 // Same positional argv as ⟨upstream⟩ irfinder.cpp main(): reads the
 // BAM stream from stdin (raw, as `gzip -cd x.bam` yields it, or BGZF with
@@ -11,6 +11,8 @@
 // (upstream's pipe has one gzip process).  --via-adapter routes every fragment through the
 // ReadBlockProcessor-shaped adapter (hip_block_processor.h) instead of handing
 // the reader's SoA batches to the engine directly; both give identical files.
+// --device-reader: the input is BGZF and is inflated, parsed and assembled on the GPU (irf_dreader_*, SURVEY §8 f N1):
+// the host only reads stdin in --feed-mb pieces (default 256) and locates the members; same files, same summary.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,14 +27,74 @@ static int die(const char* what, const char* msg) {
     return 1;
 }
 
+static void print_summary(const irf_reader_stats& st) {
+    printf("Total reads processed\t%llu\nTotal nucleotides\t%llu\nTotal singles processed\t%llu\nTotal pairs processed\t%llu\n"
+           "Short pairs\t%llu\nIntersect pairs\t%llu\nLong pairs\t%llu\nSkipped reads\t%llu\nError reads\t%llu\n",
+           (unsigned long long)st.n_records, (unsigned long long)st.n_nucleotides, (unsigned long long)st.n_singles,
+           (unsigned long long)st.n_pairs, (unsigned long long)st.n_pairs_short, (unsigned long long)st.n_pairs_intersect,
+           (unsigned long long)st.n_pairs_long, (unsigned long long)st.n_skipped, (unsigned long long)st.n_error);
+}
+
+// stdin (BGZF) -> irf_dreader -> device-resident batches -> irf_submit_batch: no record ever exists in host memory
+static int run_device_reader(const std::vector<const char*>& pos, const irf_params& P, int device, size_t feed_bytes) {
+    char err[256] = {0};
+    irf_ref* ref = nullptr;
+    if (irf_ref_load_files(pos[1], pos[2], pos[3], pos[4], &ref, err, sizeof err) != 0) return die("reference tables", err);
+    irf_ctx* ctx = nullptr;
+    int rc = irf_create(&P, ref, device, &ctx);
+    irf_ref_free(ref);
+    if (rc != 0) return die("irf_create", "no HIP device or bad parameters");
+    irf_dreader* dr = nullptr;
+    if (irf_dreader_create(&P, device, &dr) != 0) return die("irf_dreader_create", "no HIP device, or --sorted (name join is host-only)");
+    std::vector<uint8_t> buf(feed_bytes);
+    bool mapped = false;
+    while (true) {
+        size_t have = 0, n;
+        while (have < buf.size() && (n = fread(buf.data() + have, 1, buf.size() - have, stdin)) > 0) have += n;
+        if (!have) break;
+        if (irf_dreader_feed(dr, buf.data(), have) != 0) return die("BAM", irf_dreader_last_error(dr));
+        if (!mapped) {
+            const char* const* names = nullptr;
+            const uint32_t* lens = nullptr;
+            const int nc = irf_dreader_header(dr, &names, &lens);
+            if (nc >= 0) {
+                if (irf_chr_map_update(ctx, (uint32_t)nc, names, lens, nullptr) != 0) return die("irf_chr_map_update", irf_last_error(ctx));
+                mapped = true;
+            }
+        }
+        irf_batch b;
+        irf_dreader_batch(dr, &b);
+        if (b.n_frag) {
+            uint64_t id = 0;
+            if (!mapped) return die("BAM", "fragments before the header");
+            if (irf_submit_batch(ctx, &b, &id) != 0) return die("irf_submit_batch", irf_last_error(ctx));
+        }
+        // the batch lives in one of the reader's two slots: the next feed may run while this one is counted, the one
+        // after it may not
+        if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
+    }
+    if (irf_dreader_finish(dr) != 0) return die("BAM", irf_dreader_last_error(dr));
+    if (!mapped) return die("BAM", "no header");
+    if (irf_finalize(ctx) != 0) return die("irf_finalize", irf_last_error(ctx));
+    if (irf_write_outputs(ctx, pos[0]) != 0) return die("irf_write_outputs", irf_last_error(ctx));
+    irf_reader_stats st;
+    irf_dreader_get_stats(dr, &st);
+    print_summary(st);
+    irf_dreader_destroy(dr);
+    irf_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::vector<const char*> pos;
-    bool bgzf = false, via_adapter = false, sorted_input = false;
-    int device = 0, threads = 1;
+    bool bgzf = false, via_adapter = false, sorted_input = false, device_reader = false;
+    int device = 0, threads = 1, feed_mb = 256;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--bgzf")) bgzf = true;
         else if (!strcmp(argv[i], "--via-adapter")) via_adapter = true;
         else if (!strcmp(argv[i], "--sorted")) sorted_input = true;
+        else if (!strcmp(argv[i], "--device-reader")) device_reader = true;
+        else if (!strcmp(argv[i], "--feed-mb") && i + 1 < argc) feed_mb = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else pos.push_back(argv[i]);
@@ -44,6 +106,10 @@ int main(int argc, char** argv) {
     irf_params P;
     irf_params_default(&P);
     P.mate_join = sorted_input ? 1u : 0u;
+    if (device_reader) {
+        if (feed_mb < 1 || feed_mb > 16384) return die("--feed-mb", "1..16384");
+        return run_device_reader(pos, P, device, (size_t)feed_mb << 20);
+    }
     irf_reader* rd = nullptr;
     if (irf_reader_create(&P, &rd) != 0) return die("reader", "cannot create");
     if (threads != 1 && irf_reader_set_threads(rd, threads) != 0) return die("--threads", "1..64");
@@ -130,11 +196,7 @@ int main(int argc, char** argv) {
     }
     irf_reader_stats st;
     irf_reader_get_stats(rd, &st);
-    printf("Total reads processed\t%llu\nTotal nucleotides\t%llu\nTotal singles processed\t%llu\nTotal pairs processed\t%llu\n"
-           "Short pairs\t%llu\nIntersect pairs\t%llu\nLong pairs\t%llu\nSkipped reads\t%llu\nError reads\t%llu\n",
-           (unsigned long long)st.n_records, (unsigned long long)st.n_nucleotides, (unsigned long long)st.n_singles,
-           (unsigned long long)st.n_pairs, (unsigned long long)st.n_pairs_short, (unsigned long long)st.n_pairs_intersect,
-           (unsigned long long)st.n_pairs_long, (unsigned long long)st.n_skipped, (unsigned long long)st.n_error);
+    print_summary(st);
     irf_reader_destroy(rd);
     if (adapter) delete adapter; else irf_destroy(ctx);
     return 0;

@@ -251,7 +251,8 @@ def test_device_resident_batch():
 
 def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     """The command-line engine (same argv as upstream's `irfinder`) vs the oracle CLI: every output file byte-identical,
-    through the direct SoA path, through the ReadBlockProcessor adapter (hip_block_processor.h), raw and BGZF input."""
+    through the direct SoA path, through the ReadBlockProcessor adapter (hip_block_processor.h), raw and BGZF input, and
+    with the BGZF stream inflated and parsed on the device (--device-reader)."""
     import subprocess
     from irfinder_amd.synth.bam import bgzf_compress
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -277,7 +278,8 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     cpu_stdout = p.stdout
     exe = os.path.join(root, "irfinder_amd", "irfinder_hip")
     for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam"),
-                            ("sorted", ["--bgzf", "--sorted", "--threads", "4"], "sorted.bam")):
+                            ("sorted", ["--bgzf", "--sorted", "--threads", "4"], "sorted.bam"),
+                            ("device-reader", ["--device-reader"], "in.bam"), ("device-reader-1mb", ["--device-reader", "--feed-mb", "1"], "in.bam")):
         out = tmp_path / tag
         out.mkdir()
         with open(tmp_path / src, "rb") as fh:
