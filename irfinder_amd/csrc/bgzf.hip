@@ -305,101 +305,114 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
         if (btype == 3) { bad = true; break; }
         if (btype == 1) build_fixed(s_tab, lane);
         else if (build_dynamic(s_tab, lane, b) != 0) { bad = true; break; }
+        // One literal/length decode site for every lane, at the bottom of the loop, one step ahead of its use (sym).
+        // After a short match the loads of the copy are issued first, then the next symbol is decoded (bit buffer + LDS
+        // only), and only then are the loaded bytes stored: the copy's round trip to L2 runs under the decoding.  The
+        // eight loads are issued by every lane in every iteration (lanes without a deferred copy read the start of
+        // their member): a uniform instruction stream lets the wait in front of the decode name exactly the loads that
+        // are younger than the input word it needs.
+        b.refill();
+        int sym = decode_sym(s_tab, lane, LIT_LIM, LIT_BASE, LIT_SYM, b);
         while (true) {
             if (b.p > in_lim) { bad = true; break; }
-            b.refill();
-            int sym = decode_sym(s_tab, lane, LIT_LIM, LIT_BASE, LIT_SYM, b);
             if (sym < 0) { bad = true; break; }
+            const uint8_t* dsrc = obase;
+            uint8_t* ddst = obase;
+            uint32_t need = 0;                              // bytes of a deferred copy (whole 8-byte steps)
             if (sym < 256) {
                 if (op >= isize) { bad = true; break; }
                 put((uint32_t)sym);
-                continue;
+            } else {
+                if (sym == 256) break;
+                sym -= 257;
+                if (sym >= 29) { bad = true; break; }
+                uint32_t len;
+                if (sym < 8) len = 3u + (uint32_t)sym;
+                else if (sym == 28) len = 258u;
+                else {
+                    const uint32_t e = ((uint32_t)sym - 4u) >> 2;
+                    len = 3u + ((4u + ((uint32_t)sym & 3u)) << e) + b.take(e);
+                }
+                b.refill();
+                const int ds = decode_sym(s_tab, lane, DIST_LIM, DIST_BASE, DIST_SYM, b);
+                if (ds < 0 || ds >= 30) { bad = true; break; }
+                uint32_t dist;
+                if (ds < 4) dist = 1u + (uint32_t)ds;
+                else {
+                    const uint32_t e = ((uint32_t)ds - 2u) >> 1;
+                    dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + b.take(e);
+                }
+                if (dist > op || op + len > isize) { bad = true; break; }
+                flush();
+                uint8_t* dst = obase + op;
+                const uint8_t* src = dst - dist;
+                // Whole 8-byte steps may write up to 8 bytes past the end of the match as long as they stay inside the
+                // member: the output that follows overwrites them (a member that ends early is refused: op != isize).
+                const bool may_overrun = op + len + 8u <= isize;
+                op += len;
+                const uint32_t whole = (len + 7u) & ~7u;
+                if (may_overrun && whole <= 32u && dist >= whole) {
+                    dsrc = src; ddst = dst; need = whole;
+                } else {
+                    if (dist >= 8) {
+                        if (dist >= 32) {
+                            while (len >= 32) {          // one round trip per 32 bytes
+                                uint32_t w[8];
+#pragma unroll
+                                for (int k = 0; k < 8; k++) w[k] = ld32u(src + 4 * k);
+#pragma unroll
+                                for (int k = 0; k < 8; k++) st32u(dst + 4 * k, w[k]);
+                                src += 32; dst += 32; len -= 32;
+                            }
+                        }
+                        while (len >= 8) {
+                            const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
+                            st32u(dst, w0);
+                            st32u(dst + 4, w1);
+                            src += 8; dst += 8; len -= 8;
+                        }
+                        if (len && may_overrun) {
+                            const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
+                            st32u(dst, w0);
+                            st32u(dst + 4, w1);
+                            len = 0;
+                        }
+                    } else if (may_overrun) {
+                        // the match overlaps its own output: a pattern of period dist, built in registers from one load
+                        uint64_t pat = (uint64_t)ld32u(src) | (uint64_t)ld32u(src + 4) << 32;
+                        pat &= ~0ull >> (64u - 8u * dist);
+                        for (uint32_t sh = dist; sh < 8; sh <<= 1) pat |= pat << (8u * sh);
+                        const uint32_t step = dist == 3 ? 6u : dist == 5 ? 5u : dist == 6 ? 6u : dist == 7 ? 7u : 8u;   // multiple of dist
+                        while (true) {
+                            st32u(dst, (uint32_t)pat);
+                            st32u(dst + 4, (uint32_t)(pat >> 32));
+                            if (len <= step) break;
+                            dst += step; len -= step;
+                        }
+                        len = 0;
+                    }
+                    if (dist >= 4) {
+                        while (len >= 4) {
+                            st32u(dst, ld32u(src));
+                            src += 4; dst += 4; len -= 4;
+                        }
+                    }
+                    while (len) {
+                        *dst++ = *src++;
+                        len--;
+                    }
+                }
             }
-            if (sym == 256) break;
-            sym -= 257;
-            if (sym >= 29) { bad = true; break; }
-            uint32_t len;
-            if (sym < 8) len = 3u + (uint32_t)sym;
-            else if (sym == 28) len = 258u;
-            else {
-                const uint32_t e = ((uint32_t)sym - 4u) >> 2;
-                len = 3u + ((4u + ((uint32_t)sym & 3u)) << e) + b.take(e);
-            }
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = ld32u(dsrc + 4 * k);
             b.refill();
-            const int ds = decode_sym(s_tab, lane, DIST_LIM, DIST_BASE, DIST_SYM, b);
-            if (ds < 0 || ds >= 30) { bad = true; break; }
-            uint32_t dist;
-            if (ds < 4) dist = 1u + (uint32_t)ds;
-            else {
-                const uint32_t e = ((uint32_t)ds - 2u) >> 1;
-                dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + b.take(e);
-            }
-            if (dist > op || op + len > isize) { bad = true; break; }
-            flush();
-            uint8_t* dst = obase + op;
-            const uint8_t* src = dst - dist;
-            // Whole 8-byte steps may write up to 8 bytes past the end of the match as long as they stay inside the member:
-            // the output that follows overwrites them (a member that ends early is refused: op != isize).
-            const bool may_overrun = op + len + 8u <= isize;
-            op += len;
-            if (dist >= 8) {
-                if (dist >= 32) {
-                    while (len >= 32) {          // one round trip per 32 bytes
-                        uint32_t w[8];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) w[k] = ld32u(src + 4 * k);
-#pragma unroll
-                        for (int k = 0; k < 8; k++) st32u(dst + 4 * k, w[k]);
-                        src += 32; dst += 32; len -= 32;
-                    }
-                    if (len > 8 && may_overrun) {    // the rest (< 32 bytes), still one round trip
-                    const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4), w2 = ld32u(src + 8), w3 = ld32u(src + 12);
-                    st32u(dst, w0); st32u(dst + 4, w1);
-                    if (len > 16) {
-                        const uint32_t w4 = ld32u(src + 16), w5 = ld32u(src + 20), w6 = ld32u(src + 24), w7 = ld32u(src + 28);
-                        st32u(dst + 8, w2); st32u(dst + 12, w3); st32u(dst + 16, w4); st32u(dst + 20, w5);
-                        if (len > 24) { st32u(dst + 24, w6); st32u(dst + 28, w7); }
-                    } else {
-                        st32u(dst + 8, w2); st32u(dst + 12, w3);
-                    }
-                    len = 0;
-                    }
-                }
-                while (len >= 8) {
-                    const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
-                    st32u(dst, w0);
-                    st32u(dst + 4, w1);
-                    src += 8; dst += 8; len -= 8;
-                }
-                if (len && may_overrun) {
-                    const uint32_t w0 = ld32u(src), w1 = ld32u(src + 4);
-                    st32u(dst, w0);
-                    st32u(dst + 4, w1);
-                    len = 0;
-                }
-            } else if (may_overrun) {
-                // the match overlaps its own output: a pattern of period dist, built in registers from one load
-                uint64_t pat = (uint64_t)ld32u(src) | (uint64_t)ld32u(src + 4) << 32;
-                pat &= ~0ull >> (64u - 8u * dist);
-                for (uint32_t sh = dist; sh < 8; sh <<= 1) pat |= pat << (8u * sh);
-                const uint32_t step = dist == 3 ? 6u : dist == 5 ? 5u : dist == 6 ? 6u : dist == 7 ? 7u : 8u;   // multiple of dist
-                while (true) {
-                    st32u(dst, (uint32_t)pat);
-                    st32u(dst + 4, (uint32_t)(pat >> 32));
-                    if (len <= step) break;
-                    dst += step; len -= step;
-                }
-                len = 0;
-            }
-            if (dist >= 4) {
-                while (len >= 4) {
-                    st32u(dst, ld32u(src));
-                    src += 4; dst += 4; len -= 4;
-                }
-            }
-            while (len) {
-                *dst++ = *src++;
-                len--;
+            sym = decode_sym(s_tab, lane, LIT_LIM, LIT_BASE, LIT_SYM, b);
+            if (need) {
+                st32u(ddst, w[0]); st32u(ddst + 4, w[1]);
+                if (need > 8u) { st32u(ddst + 8, w[2]); st32u(ddst + 12, w[3]); }
+                if (need > 16u) { st32u(ddst + 16, w[4]); st32u(ddst + 20, w[5]); }
+                if (need > 24u) { st32u(ddst + 24, w[6]); st32u(ddst + 28, w[7]); }
             }
         }
     }
