@@ -58,18 +58,72 @@ struct Bits {
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
+// The bit buffer of the symbol loop: the next two input words (q0, q1 = the 8 bytes at p) are in registers, loaded by
+// ONE unconditional load per iteration at the bottom of the loop, so a refill is register work.  An iteration refills at
+// most twice (15 + 5 bits, refill, 15 + 13 bits, refill).
+struct FastBits {
+    const uint8_t* p;    // address of q0
+    uint64_t bb;
+    uint32_t bc, q0, q1;
+    __device__ __forceinline__ void from(const Bits& s) {
+        p = s.p - 4; bb = s.bb; bc = s.bc; q0 = s.nxt; q1 = ld32u(s.p);
+        asm volatile("" ::"v"(q0), "v"(q1));      // waited for here: nothing is pending when the symbol loop is entered
+    }
+    __device__ __forceinline__ void to(Bits& s) const {
+        s.p = p + 4; s.bb = bb; s.bc = bc; s.nxt = q0;
+    }
+    __device__ __forceinline__ void refill() {
+        if (bc <= 32) {
+            bb |= (uint64_t)q0 << bc;
+            bc += 32;
+            q0 = q1;
+            p += 4;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
 #define TAB(j) s_tab[(j) * kLanes + lane]
 
-// canonical Huffman: smallest length whose left-justified limit exceeds the next 15 bits
-__device__ __forceinline__ int decode_sym(const uint16_t* s_tab, uint32_t lane, int LIM, int BASE, int SYM, Bits& b) {
+// The 15 limits and the 15 bases of a code, in registers: the search over the limits is the dependent chain of every
+// symbol, and with one wave per SIMD (the tables of 64 lanes fill a third of the LDS) nothing hides an LDS round trip.
+struct CodeRegs {
+    uint32_t lim[15], base[15];
+};
+
+__device__ __forceinline__ void load_code_regs(const uint16_t* s_tab, uint32_t lane, int LIM, int BASE, CodeRegs& c) {
+    // (written out: the indices must be constants before the first scalar-replacement pass, or the selects below turn
+    // into indexed loads from a stack copy)
+#define IRF_LC(k) c.lim[k] = TAB(LIM + k); c.base[k] = TAB(BASE + k);
+    IRF_LC(0) IRF_LC(1) IRF_LC(2) IRF_LC(3) IRF_LC(4) IRF_LC(5) IRF_LC(6) IRF_LC(7)
+    IRF_LC(8) IRF_LC(9) IRF_LC(10) IRF_LC(11) IRF_LC(12) IRF_LC(13) IRF_LC(14)
+#undef IRF_LC
+}
+
+// canonical Huffman: smallest length whose left-justified limit exceeds the next 15 bits (binary search by selects)
+template <class B>
+__device__ __forceinline__ int decode_sym(const uint16_t* s_tab, uint32_t lane, const CodeRegs& c, int SYM, B& b) {
     const uint32_t v = __brev(b.peek(15)) >> 17;
-    uint32_t pos = 0;
-    if (TAB(LIM + 7) <= v) pos = 8;
-    if (TAB(LIM + pos + 3) <= v) pos += 4;
-    if (TAB(LIM + pos + 1) <= v) pos += 2;
-    if (TAB(LIM + pos) <= v) pos += 1;
+    // (values first: `x ? c.lim[i] : c.lim[j]` would select an address and load through it)
+    const uint32_t l0 = c.lim[0], l1 = c.lim[1], l2 = c.lim[2], l3 = c.lim[3], l4 = c.lim[4], l5 = c.lim[5], l6 = c.lim[6], l7 = c.lim[7],
+                   l8 = c.lim[8], l9 = c.lim[9], l10 = c.lim[10], l11 = c.lim[11], l12 = c.lim[12], l13 = c.lim[13], l14 = c.lim[14];
+    const uint32_t a0 = c.base[0], a1 = c.base[1], a2 = c.base[2], a3 = c.base[3], a4 = c.base[4], a5 = c.base[5], a6 = c.base[6], a7 = c.base[7],
+                   a8 = c.base[8], a9 = c.base[9], a10 = c.base[10], a11 = c.base[11], a12 = c.base[12], a13 = c.base[13], a14 = c.base[14];
+    const bool b8 = l7 <= v;
+    const bool b4 = (b8 ? l11 : l3) <= v;
+    const bool b2 = (b8 ? (b4 ? l13 : l9) : (b4 ? l5 : l1)) <= v;
+    const uint32_t e0 = b2 ? l2 : l0, e1 = b2 ? l6 : l4, e2 = b2 ? l10 : l8, e3 = b2 ? l14 : l12;
+    const bool b1 = (b8 ? (b4 ? e3 : e2) : (b4 ? e1 : e0)) <= v;
+    const uint32_t pos = (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u) + (b1 ? 1u : 0u);
     if (pos >= 15) return -1;
-    const uint32_t idx = (uint16_t)(TAB(BASE + pos) + (v >> (14 - pos)));
+    // base[pos] by the same bits
+    const uint32_t f0 = b1 ? a1 : a0, f1 = b1 ? a3 : a2, f2 = b1 ? a5 : a4, f3 = b1 ? a7 : a6;
+    const uint32_t f4 = b1 ? a9 : a8, f5 = b1 ? a11 : a10, f6 = b1 ? a13 : a12, f7 = a14;
+    const uint32_t g0 = b2 ? f1 : f0, g1 = b2 ? f3 : f2, g2 = b2 ? f5 : f4, g3 = b2 ? f7 : f6;
+    const uint32_t base = b8 ? (b4 ? g3 : g2) : (b4 ? g1 : g0);
+    const uint32_t idx = (uint16_t)(base + (v >> (14 - pos)));
     b.drop(pos + 1);
     return TAB(SYM + idx);
 }
@@ -256,7 +310,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
         return;
     }
     const uint8_t* const in0 = in + m.in_off;
-    const uint8_t* const in_lim = in0 + m.clen + 12;     // a valid stream never loads beyond this (then 4 more bytes are read)
+    const uint8_t* const in_lim = in0 + m.clen + 8;      // a valid stream never has its next input word beyond this (8 more bytes are read)
     Bits b;
     b.start(in0);
     uint8_t* const obase = out + m.out_off;
@@ -305,16 +359,22 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
         if (btype == 3) { bad = true; break; }
         if (btype == 1) build_fixed(s_tab, lane);
         else if (build_dynamic(s_tab, lane, b) != 0) { bad = true; break; }
+        CodeRegs lit, dcode;
+        load_code_regs(s_tab, lane, LIT_LIM, LIT_BASE, lit);
+        load_code_regs(s_tab, lane, DIST_LIM, DIST_BASE, dcode);
         // One literal/length decode site for every lane, at the bottom of the loop, one step ahead of its use (sym).
         // After a short match the loads of the copy are issued first, then the next symbol is decoded (bit buffer + LDS
         // only), and only then are the loaded bytes stored: the copy's round trip to L2 runs under the decoding.  The
         // eight loads are issued by every lane in every iteration (lanes without a deferred copy read the start of
-        // their member): a uniform instruction stream lets the wait in front of the decode name exactly the loads that
-        // are younger than the input word it needs.
-        b.refill();
-        int sym = decode_sym(s_tab, lane, LIT_LIM, LIT_BASE, LIT_SYM, b);
+        // their member), together with the load of the next two input words: an iteration waits for memory ONCE, after
+        // the decode, for everything it and its predecessor issued (on gfx9 stores count in vmcnt like loads, so any
+        // earlier wait for a load would also be a wait for the acknowledgement of the stores before it).
+        FastBits fb;
+        fb.from(b);
+        fb.refill();
+        int sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
         while (true) {
-            if (b.p > in_lim) { bad = true; break; }
+            if (fb.p > in_lim) { bad = true; break; }
             if (sym < 0) { bad = true; break; }
             const uint8_t* dsrc = obase;
             uint8_t* ddst = obase;
@@ -331,16 +391,16 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 else if (sym == 28) len = 258u;
                 else {
                     const uint32_t e = ((uint32_t)sym - 4u) >> 2;
-                    len = 3u + ((4u + ((uint32_t)sym & 3u)) << e) + b.take(e);
+                    len = 3u + ((4u + ((uint32_t)sym & 3u)) << e) + fb.take(e);
                 }
-                b.refill();
-                const int ds = decode_sym(s_tab, lane, DIST_LIM, DIST_BASE, DIST_SYM, b);
+                fb.refill();
+                const int ds = decode_sym(s_tab, lane, dcode, DIST_SYM, fb);
                 if (ds < 0 || ds >= 30) { bad = true; break; }
                 uint32_t dist;
                 if (ds < 4) dist = 1u + (uint32_t)ds;
                 else {
                     const uint32_t e = ((uint32_t)ds - 2u) >> 1;
-                    dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + b.take(e);
+                    dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + fb.take(e);
                 }
                 if (dist > op || op + len > isize) { bad = true; break; }
                 flush();
@@ -403,11 +463,15 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                     }
                 }
             }
+            fb.refill();
             uint32_t w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) w[k] = ld32u(dsrc + 4 * k);
-            b.refill();
-            sym = decode_sym(s_tab, lane, LIT_LIM, LIT_BASE, LIT_SYM, b);
+            const uint32_t n0 = ld32u(fb.p), n1 = ld32u(fb.p + 4);
+            sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
+            asm volatile("" ::"v"(n0), "v"(n1));      // the one wait: here, not at the next refill behind the stores below
+            fb.q0 = n0;
+            fb.q1 = n1;
             if (need) {
                 st32u(ddst, w[0]); st32u(ddst + 4, w[1]);
                 if (need > 8u) { st32u(ddst + 8, w[2]); st32u(ddst + 12, w[3]); }
@@ -415,6 +479,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 if (need > 24u) { st32u(ddst + 24, w[6]); st32u(ddst + 28, w[7]); }
             }
         }
+        fb.to(b);
     }
     flush();
     if (!bad && (op != isize || consumed_bits() > (uint64_t)m.clen * 8ull)) bad = true;
