@@ -301,11 +301,12 @@ def main():
 
     # ---------------- host decode bound (reported separately, never part of `value`) ----------------
     if world == 1 and not args.no_decode_bench:
-        from irfinder_amd.synth.bam import bgzf_compress
-        sim_seq = ReadSimulator(ann, read_len=args.read_len, stranded=bool(args.stranded), seed=seed, with_seq=True)
-        n_dec = 400_000
+        from irfinder_amd.synth.bam import bgzf_compress_mt
+        # random bases + binned qualities: compresses about as a real RNA-seq BAM does (2.4 : 1 at zlib level 6)
+        sim_seq = ReadSimulator(ann, read_len=args.read_len, stranded=bool(args.stranded), seed=seed, with_seq=2)
+        n_dec = 1_000_000
         raw = sim_seq.bam(0, n_dec)
-        z = bgzf_compress(raw)
+        z = np.frombuffer(bgzf_compress_mt(raw, 6, min(args.threads, 16)), np.uint8)
         dec = {}
         for th in (1, min(args.threads, 16)):
             rd = engine.Reader(threads=th)
@@ -314,11 +315,36 @@ def main():
                 rd.feed(z[i:i + (16 << 20)], bgzf=True)
             rd.finish()
             t1 = time.perf_counter()
+            host_stats = rd.stats()
             dec[th] = {"bgzf_MBps_in": round(len(z) / (t1 - t0) / 1e6, 1), "bam_MBps_out": round(len(raw) / (t1 - t0) / 1e6, 1),
                        "pairs_per_s": round(n_dec / (t1 - t0), 1), "threads": th}
+            rd.close()
         extra["host_decode"] = dict(dec[max(dec)], single_thread=dec[1],
                                     note="zlib inflate (worker pool, overlapped with the parser) + BAM parse + fragment assembly, "
-                                         "2x%dbp records with seq/qual; the record parser is one thread" % args.read_len)
+                                         "%d pairs of 2x%dbp records with random bases and binned qualities, BGZF at zlib level 6 "
+                                         "(%.0f MB -> %.0f MB); the record parser is one thread" % (n_dec, args.read_len, len(raw) / 1e6, len(z) / 1e6))
+        # the same bytes through the device reader (SURVEY §8 f N1): compressed BGZF in host memory -> device-resident batch
+        best = None
+        for rep in range(3):
+            dr = engine.DeviceReader()
+            t0 = time.perf_counter()
+            dr.feed(z)
+            n_dev = dr.batch_struct().n_frag
+            dr.finish()
+            t1 = time.perf_counter()
+            if best is None or t1 - t0 < best[0]:
+                best = (t1 - t0, dr.timing(), dr.stats(), n_dev)
+            dr.close()
+        dt, tm, dstats, n_dev = best
+        stages = tm["inflate_ms"] + tm["crc_ms"] + tm["chain_ms"] + tm["assemble_ms"]
+        extra["device_decode"] = {
+            "pairs_per_s": round(n_dec / dt, 1), "bam_MBps_out": round(len(raw) / dt / 1e6, 1), "bgzf_MBps_in": round(len(z) / dt / 1e6, 1),
+            "pairs_per_s_device_stages": round(n_dec / (stages / 1e3), 1), "bam_GBps_device_stages": round(len(raw) / stages / 1e6, 2),
+            "stage_ms": {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")}, "n_members": int(tm["n_members"]),
+            "same_counters_as_host_reader": dstats == host_stats, "n_frag": int(n_dev),
+            "note": "irf_dreader_*: one feed of the whole file from pageable host memory (pairs_per_s includes the H2D copy and the "
+                    "host's member scan); inflate is one lane per BGZF member, so its rate grows with the members per feed up to "
+                    "~49 k (tools/bench_dreader.py --pairs 4000000: 34 k members, 95 M pairs/s in the device stages)"}
         extra["h2d"] = {"bytes": int(in_bytes), "seconds": round(h2d_s, 4), "note": "pageable numpy -> device via torch (set-up, not timed)"}
 
     # ---------------- PCIe-inclusive rate (reported separately, never part of `value`) ----------------

@@ -64,6 +64,16 @@ def bgzf_compress(data, block=0xff00, level=1):
     return b"".join(out)
 
 
+def bgzf_compress_mt(data, level=6, threads=8, block=0xff00):
+    """bgzf_compress on a thread pool (zlib releases the GIL): same bytes as bgzf_compress(data, block, level)."""
+    from concurrent.futures import ThreadPoolExecutor
+    step = block * 64
+    mv = memoryview(data)
+    with ThreadPoolExecutor(max(1, int(threads))) as ex:
+        parts = list(ex.map(lambda i: bgzf_compress(mv[i:i + step], block, level)[:-len(BGZF_EOF)], range(0, len(data), step)))
+    return b"".join(parts) + BGZF_EOF
+
+
 def records_to_bam(chr_names, chr_lens, records):
     """records: iterable of dicts/tuples accepted by bam_record (as kwargs dicts)."""
     parts = [bam_header(chr_names, chr_lens)]

@@ -5,8 +5,6 @@ import json
 import os
 import sys
 import time
-import zlib
-from multiprocessing import Pool
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -14,29 +12,8 @@ import numpy as np
 
 from irfinder_amd import engine
 from irfinder_amd.synth.annotation import make_annotation, small_chroms
-from irfinder_amd.synth.bam import BGZF_EOF, bgzf_compress
+from irfinder_amd.synth.bam import bgzf_compress_mt
 from irfinder_amd.synth.reads import ReadSimulator
-
-LEVEL = 6
-
-
-def _comp(chunk):
-    return bgzf_compress(chunk, level=LEVEL)[:-len(BGZF_EOF)]
-
-
-def make_bgzf(raw, level, workers=16):
-    global LEVEL
-    LEVEL = level
-    step = 0xff00 * 64
-    with Pool(workers, initializer=_set_level, initargs=(level,)) as p:
-        parts = p.map(_comp, [raw[i:i + step] for i in range(0, len(raw), step)])
-    return b"".join(parts) + BGZF_EOF
-
-
-def _set_level(level):
-    global LEVEL
-    LEVEL = level
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -51,7 +28,7 @@ def main():
     sim = ReadSimulator(ann, read_len=args.read_len, seed=9, with_seq=2)
     t0 = time.perf_counter()
     raw = sim.bam(0, args.pairs)
-    z = make_bgzf(raw, args.level)
+    z = bgzf_compress_mt(raw, args.level, 16)
     print("[bench_dreader] %d pairs, %.1f MB BAM, %.1f MB BGZF (level %d), made in %.1fs" % (
         args.pairs, len(raw) / 1e6, len(z) / 1e6, args.level, time.perf_counter() - t0), file=sys.stderr, flush=True)
     zb = np.frombuffer(z, np.uint8)
