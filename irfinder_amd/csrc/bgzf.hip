@@ -304,7 +304,14 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
     const uint32_t lane = threadIdx.x;
     const uint32_t mi = blockIdx.x * kLanes + lane;
     if (mi >= n_members) return;
-    const BgzfMember m = members[mi];
+#ifndef IRF_INFLATE_EXP
+#define IRF_INFLATE_EXP 0                  // diagnostic builds only (tools/inflate_exp.sh): 1 no match copies, 2 no literal stores, 4 cached input
+#endif
+    BgzfMember m = members[mi];
+    if (IRF_INFLATE_EXP & 4) {
+        const BgzfMember a = members[mi % 128u];
+        if (a.isize == m.isize) { m.in_off = a.in_off; m.clen = a.clen; }
+    }
     if (m.isize == 0) {                    // the 28-byte EOF marker and other empty members (the host reader skips them too)
         status[mi] = BGZF_OK;
         return;
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
     auto consumed_bits = [&]() -> uint64_t { return (uint64_t)(b.p - in0 - 4) * 8ull - b.bc; };
     auto put = [&](uint32_t byte) {
         uint8_t* a = obase + op;
+        if (IRF_INFLATE_EXP & 2) { op++; return; }
         if (pn == 0 && (reinterpret_cast<uintptr_t>(a) & 3u)) {
             *a = (uint8_t)byte;
         } else {
@@ -411,7 +419,8 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 const bool may_overrun = op + len + 8u <= isize;
                 op += len;
                 const uint32_t whole = (len + 7u) & ~7u;
-                if (may_overrun && whole <= 32u && dist >= whole) {
+                if (IRF_INFLATE_EXP & 1) {
+                } else if (may_overrun && whole <= 32u && dist >= whole) {
                     dsrc = src; ddst = dst; need = whole;
                 } else {
                     if (dist >= 8) {
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             fb.refill();
             uint32_t w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = ld32u(dsrc + 4 * k);
+            for (int k = 0; k < 8; k++) w[k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(dsrc + 4 * k);
             const uint32_t n0 = ld32u(fb.p), n1 = ld32u(fb.p + 4);
             sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
             asm volatile("" ::"v"(n0), "v"(n1));      // the one wait: here, not at the next refill behind the stores below

@@ -12,6 +12,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -287,6 +288,9 @@ int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
     uint32_t first_bad = 0;
     HIP_TRY(hipMemcpyAsync(&first_bad, f_first_bad, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+#ifdef IRF_INFLATE_EXP
+    { float ms_ = 0; (void)hipEventElapsedTime(&ms_, ev[1], ev[2]); fprintf(stderr, "[inflate_exp %d] %u members, inflate %.3f ms\n", IRF_INFLATE_EXP, n_members, ms_); }
+#endif
     if (first_bad != 0xffffffffu) {
         uint32_t why = 0;
         HIP_TRY(hipMemcpy(&why, d_status.p + first_bad, 4, hipMemcpyDeviceToHost));
