@@ -351,6 +351,16 @@ int irf_dreader_create(const irf_params* params, int device, irf_dreader** out);
 void irf_dreader_destroy(irf_dreader* r);
 const char* irf_dreader_last_error(const irf_dreader* r);
 int irf_dreader_feed(irf_dreader* r, const uint8_t* bgzf, size_t len);
+/* Pipeline (off by default; set before the first feed, else IRF_E_STATE).  On: a
+ * feed copies and inflates ITS bytes and then parses the bytes of the feed
+ * BEFORE it, so the host-to-device copy of one feed overlaps the inflate of the
+ * previous one.  irf_dreader_batch after feed k then holds the fragments of
+ * feed k - 1 (none after the first), irf_dreader_finish parses the last feed,
+ * and its fragments are the batch after finish; errors of a feed surface one
+ * call later.  Same fragments in the same order as with the pipeline off.  The
+ * bytes passed to a feed may be reused as soon as it returns, in both modes.
+ * No upstream counterpart (upstream reads a pipe synchronously).              */
+int irf_dreader_set_pipeline(irf_dreader* r, int on);
 int irf_dreader_header(const irf_dreader* r, const char* const** names, const uint32_t** lens);
 /* Fragments of the LAST feed (possibly none), device-resident.               */
 int irf_dreader_batch(const irf_dreader* r, irf_batch* out);

@@ -60,6 +60,8 @@ struct TwoSpan {
     }
 };
 
+constexpr uint64_t kMinGap = 1ull << 20;    // bytes kept free in front of a slot's inflated members for the predecessor's carry
+
 inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
 inline uint32_t rd32(const uint8_t* p) { return rd16(p) | rd16(p + 2) << 16; }
 
@@ -130,25 +132,40 @@ struct irf_dreader {
     irf_reader_stats stats;
     irf_dreader_timing timing;
 
-    // device side
-    DBuf<uint8_t> d_in, d_raw[2];
-    int cur = 0;
-    uint64_t carry_len = 0;                  // bytes at the front of d_raw[cur]
+    // device side.  A feed is two stages: stage 1 (compressed bytes to the device on the copy stream, inflate + CRC on
+    // the inflate stream) needs nothing from the feeds before it; stage 2 (record chain, pairing, assembly on `stream`)
+    // needs the carry of its predecessor.  With the pipeline on, stage 1 of feed k runs before stage 2 of feed k - 1,
+    // so the copy of feed k + 1 and the inflate of feed k overlap.  The inflated members of a slot start at a fixed
+    // offset `gap`; the carry of the predecessor is placed right in front of them.
+    struct InSlot {
+        DBuf<uint8_t> d_in, raw;
+        DBuf<dev::BgzfMember> d_members;
+        DBuf<uint32_t> d_status, d_first_bad;
+        uint32_t n_members = 0;
+        uint64_t total_out = 0, gap = 0;
+        size_t consumed_in = 0;
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // copy begin / end, inflate begin / end, CRC end
+    } slot[2];
+    int next_slot = 0, inflight = -1;        // inflight: slot whose stage 2 is still to run
+    bool pipeline = false, fed = false;
+    hipStream_t s_copy = nullptr, s_inf = nullptr;
+    DBuf<uint8_t> d_carry;                   // what the last stage 2 left unconsumed
+    uint64_t carry_len = 0;
     bool carry_dangling = false;             // the carry starts with a complete first mate that waits for its mate
     bool carry_partial = false;              // ... and / or ends with an incomplete record
-    DBuf<dev::BgzfMember> d_members;
-    DBuf<uint32_t> d_status, d_count, d_seg_base, d_rec_nf, d_tile_last, d_tile_carry, d_fr, d_bl, d_ws;
+    DBuf<uint32_t> d_count, d_seg_base, d_rec_nf, d_tile_last, d_tile_carry, d_fr, d_bl, d_ws;
     DBuf<uint64_t> d_guess, d_exit, d_rec_off;
     DBuf<unsigned long long> d_scal;         // [0] record error, [1 .. 1 + RS_COUNT) reader statistics
-    DBuf<uint32_t> d_flags;                  // [0] chain changed, [1] first bad member, [2] dangling
+    DBuf<uint32_t> d_flags;                  // [0] chain changed, [2] dangling
     OutSlot out[2];
     int out_cur = 0;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};      // stage 2: begin, chain done, assembled
 
     int fail(int code, const std::string& msg) { err = msg; failed = true; return code; }
     int init();
     int feed(const uint8_t* data, size_t len);
-    int process(const TwoSpan& in, size_t consumed_in);
+    int stage1(InSlot& S, const TwoSpan& in, size_t consumed_in);
+    int stage2(InSlot& S);
     int finish();
     int host_header(const TwoSpan& in, size_t n_members_avail);
 };
@@ -167,7 +184,13 @@ struct irf_dreader {
 int irf_dreader::init() {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s_inf, hipStreamNonBlocking));
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& S : slot) {
+        for (auto& e : S.ev) HIP_TRY(hipEventCreate(&e));
+        MEM_TRY(S.d_first_bad.reserve(4));
+    }
     memset(&stats, 0, sizeof stats);
     memset(&timing, 0, sizeof timing);
     MEM_TRY(d_scal.reserve(1 + dev::RS_COUNT));
@@ -215,12 +238,13 @@ int irf_dreader::host_header(const TwoSpan& in, size_t n_avail) {
 int irf_dreader::feed(const uint8_t* data, size_t len) {
     if (failed) return IRF_E_PARSE;
     HIP_TRY(hipSetDevice(device));
+    fed = true;
     const TwoSpan in{pending.data(), pending.size(), data, len};
     zblocks.clear();
     size_t scan = 0, total_out = 0;
     const std::string scan_error = locate_members(in, scan, total_out, zblocks);
     if (!scan_error.empty()) return fail(IRF_E_PARSE, scan_error);
-    out[out_cur ^ 1].n_frag = out[out_cur ^ 1].n_blk = 0;
+    out[out_cur ^ 1].n_frag = out[out_cur ^ 1].n_blk = 0;          // the batch of this feed: empty unless a stage 2 fills it
     bool consume = !zblocks.empty();
     if (consume && !header_done) {
         int rc = host_header(in, zblocks.size());
@@ -232,73 +256,105 @@ int irf_dreader::feed(const uint8_t* data, size_t len) {
         out_cur ^= 1;
         return 0;
     }
-    int rc = process(in, scan);
+    const int cur = next_slot;
+    next_slot ^= 1;
+    int rc = stage1(slot[cur], in, scan);
     if (rc != 0) return rc;
-    // what is left behind the last complete member
+    // what is left behind the last complete member (stage 1 has read the caller's bytes)
     if (scan >= in.na) {
         pending.assign(data + (scan - in.na), data + len);
     } else {
         pending.erase(pending.begin(), pending.begin() + (ptrdiff_t)scan);
         pending.insert(pending.end(), data, data + len);
     }
+    if (pipeline) {
+        const int prev = inflight;
+        inflight = cur;
+        if (prev >= 0 && (rc = stage2(slot[prev])) != 0) return rc;
+    } else if ((rc = stage2(slot[cur])) != 0) {
+        return rc;
+    }
+    out_cur ^= 1;
     return 0;
 }
 
-int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
+// Stage 1: compressed bytes + member table to the device, inflate, CRC.  Returns when the caller's bytes have been read;
+// the kernels may still be running.
+int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in) {
     const uint32_t n_members = (uint32_t)zblocks.size();
+    // room for the predecessor's carry in front of the inflated members: known when the pipeline is off; with the
+    // pipeline on it is not yet (stage 2 moves the members in the rare case that the carry does not fit)
+    const uint64_t gap = std::max<uint64_t>(kMinGap, (carry_len + 4095) & ~4095ull);
     members.resize(n_members);
     uint64_t total_out = 0;
     for (uint32_t i = 0; i < n_members; i++) {
         const irf::ZBlock& b = zblocks[i];
-        members[i] = dev::BgzfMember{b.in_off, carry_len + b.out_off, (uint32_t)b.clen, b.isize, b.crc, 0};
+        members[i] = dev::BgzfMember{b.in_off, gap + b.out_off, (uint32_t)b.clen, b.isize, b.crc, 0};
         total_out += b.isize;
     }
-    const uint64_t total = carry_len + total_out;
-    MEM_TRY(d_in.reserve(consumed_in + dev::kInflateSlack));
-    MEM_TRY(d_members.reserve(n_members));
-    MEM_TRY(d_status.reserve(n_members));
-    if (d_raw[cur].cap < total + 64) {
-        // grow, keeping the carry at the front
-        DBuf<uint8_t> bigger;
-        MEM_TRY(bigger.reserve(total + 64));
-        if (carry_len) HIP_TRY(hipMemcpyAsync(bigger.p, d_raw[cur].p, carry_len, hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        std::swap(d_raw[cur].p, bigger.p);
-        std::swap(d_raw[cur].cap, bigger.cap);
-    }
-    uint8_t* const raw = d_raw[cur].p;
-    uint32_t* const f_changed = d_flags.p, *const f_first_bad = d_flags.p + 1, *const f_dangling = d_flags.p + 2;
+    MEM_TRY(S.d_in.reserve(consumed_in + dev::kInflateSlack));
+    MEM_TRY(S.d_members.reserve(n_members));
+    MEM_TRY(S.d_status.reserve(n_members));
+    MEM_TRY(S.raw.reserve(gap + total_out + 64));
+    S.n_members = n_members; S.total_out = total_out; S.gap = gap; S.consumed_in = consumed_in;
 
-    HIP_TRY(hipEventRecord(ev[0], stream));
+    HIP_TRY(hipEventRecord(S.ev[0], s_copy));
     {
         const size_t from_a = std::min(in.na, consumed_in);
-        if (from_a) HIP_TRY(hipMemcpyAsync(d_in.p, in.a, from_a, hipMemcpyHostToDevice, stream));
-        if (consumed_in > from_a) HIP_TRY(hipMemcpyAsync(d_in.p + from_a, in.b, consumed_in - from_a, hipMemcpyHostToDevice, stream));
+        if (from_a) HIP_TRY(hipMemcpyAsync(S.d_in.p, in.a, from_a, hipMemcpyHostToDevice, s_copy));
+        if (consumed_in > from_a) HIP_TRY(hipMemcpyAsync(S.d_in.p + from_a, in.b, consumed_in - from_a, hipMemcpyHostToDevice, s_copy));
     }
-    HIP_TRY(hipMemsetAsync(d_in.p + consumed_in, 0, dev::kInflateSlack, stream));
-    HIP_TRY(hipMemcpyAsync(d_members.p, members.data(), sizeof(dev::BgzfMember) * n_members, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(f_first_bad, 0xff, 4, stream));
-    HIP_TRY(hipEventRecord(ev[1], stream));
-    dev::launch_bgzf_inflate(d_in.p, d_members.p, n_members, raw, d_status.p, stream);
-    HIP_TRY(hipEventRecord(ev[2], stream));
-    dev::launch_bgzf_crc(raw, d_members.p, n_members, d_status.p, stream);
-    dev::launch_first_bad(d_status.p, n_members, f_first_bad, stream);
-    HIP_TRY(hipEventRecord(ev[3], stream));
+    HIP_TRY(hipMemsetAsync(S.d_in.p + consumed_in, 0, dev::kInflateSlack, s_copy));
+    HIP_TRY(hipMemcpyAsync(S.d_members.p, members.data(), sizeof(dev::BgzfMember) * n_members, hipMemcpyHostToDevice, s_copy));
+    HIP_TRY(hipMemsetAsync(S.d_first_bad.p, 0xff, 4, s_copy));
+    HIP_TRY(hipEventRecord(S.ev[1], s_copy));
+    HIP_TRY(hipStreamWaitEvent(s_inf, S.ev[1], 0));
+    HIP_TRY(hipEventRecord(S.ev[2], s_inf));
+    dev::launch_bgzf_inflate(S.d_in.p, S.d_members.p, n_members, S.raw.p, S.d_status.p, s_inf);
+    HIP_TRY(hipEventRecord(S.ev[3], s_inf));
+    dev::launch_bgzf_crc(S.raw.p, S.d_members.p, n_members, S.d_status.p, s_inf);
+    dev::launch_first_bad(S.d_status.p, n_members, S.d_first_bad.p, s_inf);
+    HIP_TRY(hipEventRecord(S.ev[4], s_inf));
     HIP_TRY(hipGetLastError());
+    // the caller's bytes (and `members`) may change once this returns, whatever kind of host memory they are in
+    HIP_TRY(hipEventSynchronize(S.ev[1]));
+    return 0;
+}
+
+// Stage 2: [carry | inflated members] -> fragments of out[out_cur ^ 1], new carry.  Synchronous.
+int irf_dreader::stage2(InSlot& S) {
+    const uint32_t n_members = S.n_members;
+    uint32_t* const f_changed = d_flags.p, *const f_dangling = d_flags.p + 2;
+    HIP_TRY(hipStreamWaitEvent(stream, S.ev[4], 0));
     uint32_t first_bad = 0;
-    HIP_TRY(hipMemcpyAsync(&first_bad, f_first_bad, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&first_bad, S.d_first_bad.p, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
 #ifdef IRF_INFLATE_EXP
-    { float ms_ = 0; (void)hipEventElapsedTime(&ms_, ev[1], ev[2]); fprintf(stderr, "[inflate_exp %d] %u members, inflate %.3f ms\n", IRF_INFLATE_EXP, n_members, ms_); }
+    { float ms_ = 0; (void)hipEventElapsedTime(&ms_, S.ev[2], S.ev[3]); fprintf(stderr, "[inflate_exp %d] %u members, inflate %.3f ms\n", IRF_INFLATE_EXP, n_members, ms_); }
 #endif
     if (first_bad != 0xffffffffu) {
         uint32_t why = 0;
-        HIP_TRY(hipMemcpy(&why, d_status.p + first_bad, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&why, S.d_status.p + first_bad, 4, hipMemcpyDeviceToHost));
         return fail(IRF_E_PARSE, why == dev::BGZF_BAD_CRC ? "BGZF: CRC mismatch" : "BGZF: inflate failed");
     }
+    if (carry_len > S.gap) {
+        // (pipeline only) the carry is longer than the room left for it: move the members behind a larger gap
+        const uint64_t gap = (carry_len + 4095) & ~4095ull;
+        DBuf<uint8_t> bigger;
+        MEM_TRY(bigger.reserve(gap + S.total_out + 64));
+        if (S.total_out) HIP_TRY(hipMemcpyAsync(bigger.p + gap, S.raw.p + S.gap, S.total_out, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::swap(S.raw.p, bigger.p);
+        std::swap(S.raw.cap, bigger.cap);
+        S.gap = gap;
+    }
+    uint8_t* const raw = S.raw.p;
+    HIP_TRY(hipEventRecord(ev[0], stream));
+    if (carry_len) HIP_TRY(hipMemcpyAsync(raw + (S.gap - carry_len), d_carry.p, carry_len, hipMemcpyDeviceToDevice, stream));
+    const uint64_t total = S.gap + S.total_out;
 
     // ---- record chain ----
-    const uint64_t start = header_skipped ? 0 : header_len;
+    const uint64_t start = header_skipped ? S.gap - carry_len : S.gap + header_len;
     header_skipped = true;
     const int32_t n_ref = (int32_t)chr_names.size();
     uint32_t n_rec = 0;
@@ -333,7 +389,7 @@ int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
         HIP_TRY(hipMemcpyAsync(&tail_off, d_exit.p + (n_seg - 1), 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
-    HIP_TRY(hipEventRecord(ev[4], stream));
+    HIP_TRY(hipEventRecord(ev[1], stream));
 
     // ---- records -> fragments ----
     OutSlot& O = out[out_cur ^ 1];
@@ -384,7 +440,7 @@ int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
     A.frag_chr = O.frag_chr.p; A.frag_flags = O.frag_flags.p; A.frag_start = O.frag_start.p; A.frag_end = O.frag_end.p;
     A.frag_blk_off = O.frag_blk_off.p; A.blk_start = O.blk_start.p; A.blk_len = O.blk_len.p; A.blk_read = O.blk_read.p;
     dev::launch_assemble_write(A, n_frag, n_blk, stream);
-    HIP_TRY(hipEventRecord(ev[5], stream));
+    HIP_TRY(hipEventRecord(ev[2], stream));
     O.n_frag = n_frag; O.n_blk = n_blk;
 
     // ---- carry: everything behind the last complete unit ----
@@ -393,15 +449,13 @@ int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
     HIP_TRY(hipStreamSynchronize(stream));
     const uint64_t new_carry = total - tail_from;
     if (new_carry) {
-        MEM_TRY(d_raw[cur ^ 1].reserve(new_carry + 64));
-        HIP_TRY(hipMemcpyAsync(d_raw[cur ^ 1].p, raw + tail_from, new_carry, hipMemcpyDeviceToDevice, stream));
+        MEM_TRY(d_carry.reserve(new_carry + 64));
+        HIP_TRY(hipMemcpyAsync(d_carry.p, raw + tail_from, new_carry, hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
-    cur ^= 1;
     carry_len = new_carry;
     carry_dangling = dangling != 0;
     carry_partial = tail_off != total;
-    out_cur ^= 1;
 
     stats.n_records += scal[1 + dev::RS_RECORDS]; stats.n_nucleotides += scal[1 + dev::RS_NUCLEOTIDES];
     stats.n_singles += scal[1 + dev::RS_SINGLES]; stats.n_pairs += scal[1 + dev::RS_PAIRS];
@@ -409,19 +463,29 @@ int irf_dreader::process(const TwoSpan& in, size_t consumed_in) {
     stats.n_pairs_long += scal[1 + dev::RS_LONG]; stats.n_skipped += scal[1 + dev::RS_SKIPPED]; stats.n_error += scal[1 + dev::RS_ERROR];
 
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); timing.h2d_ms += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); timing.inflate_ms += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); timing.crc_ms += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); timing.chain_ms += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); timing.assemble_ms += ms;
-    timing.bytes_in += consumed_in;
-    timing.bytes_inflated += total_out;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); timing.h2d_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); timing.inflate_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); timing.crc_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); timing.chain_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); timing.assemble_ms += ms;
+    timing.bytes_in += S.consumed_in;
+    timing.bytes_inflated += S.total_out;
     timing.n_members += n_members;
     return 0;
 }
 
 int irf_dreader::finish() {
     if (failed) return IRF_E_PARSE;
+    if (inflight >= 0) {
+        // pipeline: the last feed's stage 2; its fragments are the batch after this call
+        HIP_TRY(hipSetDevice(device));
+        out[out_cur ^ 1].n_frag = out[out_cur ^ 1].n_blk = 0;
+        const int prev = inflight;
+        inflight = -1;
+        const int rc = stage2(slot[prev]);
+        if (rc != 0) return rc;
+        out_cur ^= 1;
+    }
     if (!pending.empty()) return fail(IRF_E_PARSE, "BGZF: truncated block at end of input");
     if (!header_done) return fail(IRF_E_PARSE, "BAM: truncated header");
     if (carry_partial) return fail(IRF_E_PARSE, "BAM: truncated record at end of input");
@@ -429,7 +493,7 @@ int irf_dreader::finish() {
         // the first mate is a record like any other: count it, and the read as an error (as the host reader does)
         int32_t l_seq = 0;
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipMemcpy(&l_seq, d_raw[cur].p + 20, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&l_seq, d_carry.p + 20, 4, hipMemcpyDeviceToHost));
         stats.n_records++;
         if (l_seq > 0) stats.n_nucleotides += (uint64_t)l_seq;
         stats.n_error++;
@@ -464,8 +528,10 @@ int irf_dreader_create(const irf_params* params, int device, irf_dreader** out) 
 void irf_dreader_destroy(irf_dreader* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    for (hipStream_t st : {r->s_copy, r->s_inf, r->stream})
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto& e : r->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& S : r->slot) for (auto& e : S.ev) if (e) (void)hipEventDestroy(e);
     delete r;
 }
 
@@ -474,6 +540,13 @@ const char* irf_dreader_last_error(const irf_dreader* r) { return r ? r->err.c_s
 int irf_dreader_feed(irf_dreader* r, const uint8_t* bgzf, size_t len) {
     if (!r || (!bgzf && len)) return IRF_E_ARG;
     return r->feed(bgzf, len);
+}
+
+int irf_dreader_set_pipeline(irf_dreader* r, int on) {
+    if (!r) return IRF_E_ARG;
+    if (r->fed) return IRF_E_STATE;
+    r->pipeline = on != 0;
+    return 0;
 }
 
 int irf_dreader_header(const irf_dreader* r, const char* const** names, const uint32_t** lens) {

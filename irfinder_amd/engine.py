@@ -104,6 +104,7 @@ def lib():
     L.irf_dreader_last_error.argtypes = [vp]
     L.irf_dreader_last_error.restype = C.c_char_p
     L.irf_dreader_feed.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.irf_dreader_set_pipeline.argtypes = [vp, C.c_int]
     L.irf_dreader_header.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(u32))]
     L.irf_dreader_batch.argtypes = [vp, C.POINTER(IrfBatch)]
     L.irf_dreader_finish.argtypes = [vp]
@@ -273,13 +274,17 @@ def gpu_bgzf_inflate(data, device=0):
 class DeviceReader:
     """Device reader (irf_dreader_*): compressed BGZF bytes in, DEVICE-resident fragment batches out."""
 
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, pipeline=False):
+        """pipeline: irf_dreader_set_pipeline — the batch after feed k is that of feed k - 1, the last one appears after
+        finish(); the copy of a feed overlaps the inflate of the feed before it."""
         self.L = lib()
         self.params = params or default_params()
         self.h = C.c_void_p()
         rc = self.L.irf_dreader_create(C.byref(self.params), int(device), C.byref(self.h))
         if rc != 0:
             raise IrfError(rc, "irf_dreader_create failed (no HIP device, or params.mate_join set)")
+        if pipeline:
+            self._chk(self.L.irf_dreader_set_pipeline(self.h, 1))
 
     def _chk(self, rc):
         if rc != 0:

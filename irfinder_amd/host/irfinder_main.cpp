@@ -46,13 +46,12 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
     if (rc != 0) return die("irf_create", "no HIP device or bad parameters");
     irf_dreader* dr = nullptr;
     if (irf_dreader_create(&P, device, &dr) != 0) return die("irf_dreader_create", "no HIP device, or --sorted (name join is host-only)");
+    // pipelined: while a piece is copied and inflated, the fragments of the piece before it are assembled and counted,
+    // and stdin is read for the next one
+    if (irf_dreader_set_pipeline(dr, 1) != 0) return die("irf_dreader_set_pipeline", irf_dreader_last_error(dr));
     std::vector<uint8_t> buf(feed_bytes);
     bool mapped = false;
-    while (true) {
-        size_t have = 0, n;
-        while (have < buf.size() && (n = fread(buf.data() + have, 1, buf.size() - have, stdin)) > 0) have += n;
-        if (!have) break;
-        if (irf_dreader_feed(dr, buf.data(), have) != 0) return die("BAM", irf_dreader_last_error(dr));
+    auto take_batch = [&]() -> int {
         if (!mapped) {
             const char* const* names = nullptr;
             const uint32_t* lens = nullptr;
@@ -69,11 +68,21 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
             if (!mapped) return die("BAM", "fragments before the header");
             if (irf_submit_batch(ctx, &b, &id) != 0) return die("irf_submit_batch", irf_last_error(ctx));
         }
-        // the batch lives in one of the reader's two slots: the next feed may run while this one is counted, the one
-        // after it may not
+        return 0;
+    };
+    while (true) {
+        size_t have = 0, n;
+        while (have < buf.size() && (n = fread(buf.data() + have, 1, buf.size() - have, stdin)) > 0) have += n;
+        if (!have) break;
+        // the batch submitted last lives in one of the reader's two slots: this feed fills the other one, so the
+        // count kernel of that batch must have finished only before the feed after this one
         if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
+        if (irf_dreader_feed(dr, buf.data(), have) != 0) return die("BAM", irf_dreader_last_error(dr));
+        if (int rc = take_batch()) return rc;
     }
+    if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
     if (irf_dreader_finish(dr) != 0) return die("BAM", irf_dreader_last_error(dr));
+    if (int rc = take_batch()) return rc;
     if (!mapped) return die("BAM", "no header");
     if (irf_finalize(ctx) != 0) return die("irf_finalize", irf_last_error(ctx));
     if (irf_write_outputs(ctx, pos[0]) != 0) return die("irf_write_outputs", irf_last_error(ctx));

@@ -43,9 +43,10 @@ def host_read(z, **over):
     return r.header(), r.take_batch(), r.stats()
 
 
-def device_read(z, pieces=None, **over):
-    """pieces: iterable of chunk sizes (cycled); None = one feed."""
-    d = engine.DeviceReader(engine.default_params(**over))
+def device_read(z, pieces=None, pipeline=False, **over):
+    """pieces: iterable of chunk sizes (cycled); None = one feed.  pipeline: irf_dreader_set_pipeline (the batch after a
+    feed is the one of the feed before it, the last one appears after finish)."""
+    d = engine.DeviceReader(engine.default_params(**over), pipeline=pipeline)
     out, pos, k = [], 0, 0
     while pos < len(z):
         n = len(z) if pieces is None else int(pieces[k % len(pieces)])
@@ -53,7 +54,11 @@ def device_read(z, pieces=None, **over):
         out.append(d.batch_to_host())
         pos += n
         k += 1
+    if pipeline:
+        assert out[0].n_frag == 0
     d.finish()
+    if pipeline:
+        out.append(d.batch_to_host())
     return d.header(), concat(out), d.stats(), d
 
 
@@ -143,8 +148,9 @@ def test_device_reader_ragged_feeds_and_member_sizes():
     for block, pieces in ((20000, [len(bam)]), (0xff00, [70001, 13, 250000]), (3000, [4096]), (700, [1, 7, 50000, 333]),
                           (0xff00, [100])):
         z = bgzf_compress(bam, block=block, level=1)
-        _, db, ds, _ = device_read(z, pieces)
-        assert db.equals(ob) and ds == ost, (block, pieces)
+        for pipeline in (False, True):
+            _, db, ds, _ = device_read(z, pieces, pipeline)
+            assert db.equals(ob) and ds == ost, (block, pieces, pipeline)
 
 
 def test_device_reader_edge_records_and_switches():
@@ -158,9 +164,9 @@ def test_device_reader_edge_records_and_switches():
             dict(ref_id=0, pos=1, flag=0x41, cigar="10M")]                                                   # dangling mate
     bam = records_to_bam(chrs, lens, recs)
     ob, ost, rc = orc.bam_to_batch(bam)
-    for pieces in (None, [1], [29]):
-        _, db, ds, _ = device_read(bgzf_compress(bam, block=64), pieces)
-        assert db.equals(ob) and ds == ost, pieces
+    for pieces, pipeline in ((None, False), ([1], False), ([29], False), (None, True), ([29], True), ([400, 3], True)):
+        _, db, ds, _ = device_read(bgzf_compress(bam, block=64), pieces, pipeline)
+        assert db.equals(ob) and ds == ost, (pieces, pipeline)
     assert ost["n_error"] == 2 + 1 + 1 + 1 and ost["n_skipped"] == 2 and ob.n_frag == 2
     # header only; header spread over many members
     (dn, dl), db, ds, _ = device_read(bgzf_compress(records_to_bam(chrs, lens, []), block=5))
@@ -204,8 +210,8 @@ def test_device_reader_record_payload_that_looks_like_records():
     bam = bytes(bam)
     ob, ost, rc = orc.bam_to_batch(bam)
     assert rc == 0 and ob.n_frag == 3000
-    for pieces in (None, [5000]):
-        _, db, ds, _ = device_read(bgzf_compress(bam, block=0x4000), pieces)
+    for pieces, pipeline in ((None, False), ([5000], False), ([5000], True)):
+        _, db, ds, _ = device_read(bgzf_compress(bam, block=0x4000), pieces, pipeline)
         assert db.equals(ob) and ds == ost
 
 
@@ -250,15 +256,67 @@ def test_device_reader_fault_injection():
             d.finish()
 
 
-def test_device_reader_feeds_the_engine_without_a_host_copy():
+def test_device_reader_pipeline_errors_and_long_carry():
+    """Pipeline on: errors of a feed surface one call later (next feed or finish); a carry longer than the room kept for
+    it in front of the next feed's members (a 1.8 MB record cut by many feeds) takes the path that moves the members."""
+    ann, sim = small_world(seed=5)
+    bam = sim.bam(0, 2000)
+    z = bgzf_compress(bam, block=4000)
+    bad = bytearray(z)
+    bad[len(z) // 2] ^= 0xff
+    d = engine.DeviceReader(pipeline=True)
+    d.feed(bytes(bad))                                         # copied and inflated; not looked at yet
+    with pytest.raises(engine.IrfError, match="BGZF"):
+        d.finish()
+    d = engine.DeviceReader(pipeline=True)
+    d.feed(bytes(bad[:len(z) // 4]))
+    with pytest.raises(engine.IrfError, match="BGZF"):
+        d.feed(bytes(bad[len(z) // 4:]))                       # inflates the second piece, parses the first: fine ...
+        d.finish()                                             # ... the corrupt member is met here
+    d = engine.DeviceReader(pipeline=True)
+    d.feed(bgzf_compress(bam[:-5], block=4000))
+    with pytest.raises(engine.IrfError, match="truncated record"):
+        d.finish()
+    d = engine.DeviceReader()
+    d.feed(z[:100])
+    with pytest.raises(engine.IrfError):
+        d._chk(d.L.irf_dreader_set_pipeline(d.h, 1))           # only before the first feed
+    # one very long record between ordinary ones
+    chrs, lens = ["c1"], [1 << 22]
+    recs = [dict(ref_id=0, pos=1000 + 9 * i, flag=0x0, cigar="80M200N70M", name="a%d" % i, l_seq=150) for i in range(50)]
+    recs.append(dict(ref_id=0, pos=5000, flag=0x10, cigar="100M1000N100M", name="long", l_seq=1_200_000))
+    recs += [dict(ref_id=0, pos=6000 + 9 * i, flag=0x0, cigar="75M", name="b%d" % i, l_seq=75) for i in range(50)]
+    raw = bytearray(records_to_bam(chrs, lens, recs))
+    rng = np.random.default_rng(8)
+    o = len(records_to_bam(chrs, lens, []))
+    while o < len(raw):
+        bs, = struct.unpack_from("<i", raw, o)
+        if bs > 1_000_000:                                     # incompressible sequence + quality bytes
+            pay = o + 36 + raw[o + 12] + 4 * 3
+            raw[pay:o + 4 + bs] = rng.integers(0, 256, o + 4 + bs - pay, dtype=np.uint8).tobytes()
+        o += 4 + bs
+    raw = bytes(raw)
+    ob, ost, rc = orc.bam_to_batch(raw)
+    assert rc == 0 and ob.n_frag == 101
+    z = bgzf_compress(raw, block=0xff00, level=1)
+    assert len(z) > 1_700_000
+    for pieces, pipeline in (([300_000], True), ([300_000], False), ([1_000_000, 50_000], True)):
+        _, db, ds, _ = device_read(z, pieces, pipeline)
+        assert db.equals(ob) and ds == ost, (pieces, pipeline)
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_device_reader_feeds_the_engine_without_a_host_copy(pipeline):
     """compressed bytes -> irf_dreader -> DEVICE batch -> irf_submit_batch -> IR table == oracle on the same BAM."""
     ann, sim = small_world(seed=3, with_seq=2)
     bam = sim.bam(0, 40000)
     z = bgzf_compress(bam, block=0xff00, level=6)
-    d = engine.DeviceReader()
+    d = engine.DeviceReader(pipeline=pipeline)
     e = None
     step = 1 << 20
     for pos in range(0, len(z), step):
+        if e is not None:
+            e.sync()                                          # the batch before the last one is overwritten by this feed
         d.feed(z[pos:pos + step])
         if e is None:
             names, lens = d.header()
@@ -267,8 +325,12 @@ def test_device_reader_feeds_the_engine_without_a_host_copy():
         b = d.batch_struct()
         if b.n_frag:
             e.submit(b)
-        e.sync()                                              # (two slots would allow one feed of overlap)
+    e.sync()
     d.finish()
+    if pipeline:
+        b = d.batch_struct()
+        assert b.n_frag
+        e.submit(b)
     e.finalize()
     g = e.results()
     ob, _, _ = orc.bam_to_batch(bam)

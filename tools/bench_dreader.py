@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--host-threads", type=int, default=16)
+    ap.add_argument("--pipeline", type=int, default=0, help="1: irf_dreader_set_pipeline (copy of a piece overlaps the inflate of the one before)")
     args = ap.parse_args()
     ann = make_annotation(small_chroms(4, 20_000_000), seed=9)
     sim = ReadSimulator(ann, read_len=args.read_len, seed=9, with_seq=2)
@@ -33,17 +34,19 @@ def main():
         args.pairs, len(raw) / 1e6, len(z) / 1e6, args.level, time.perf_counter() - t0), file=sys.stderr, flush=True)
     zb = np.frombuffer(z, np.uint8)
     piece = args.piece << 20 if args.piece else len(z)
-    out = {"pairs": args.pairs, "bam_MB": round(len(raw) / 1e6, 1), "bgzf_MB": round(len(z) / 1e6, 1), "level": args.level,
+    out = {"pairs": args.pairs, "bam_MB": round(len(raw) / 1e6, 1), "bgzf_MB": round(len(z) / 1e6, 1), "level": args.level, "pipeline": args.pipeline,
            "piece_MB": args.piece or round(len(z) / 1e6, 1)}
     best = None
     for rep in range(args.reps):
-        d = engine.DeviceReader()
+        d = engine.DeviceReader(pipeline=bool(args.pipeline))
         t0 = time.perf_counter()
         n_frag = 0
         for i in range(0, len(z), piece):
             d.feed(zb[i:i + piece])
             n_frag += d.batch_struct().n_frag
         d.finish()
+        if args.pipeline:
+            n_frag += d.batch_struct().n_frag
         dt = time.perf_counter() - t0
         t = d.timing()
         st = d.stats()
