@@ -12,6 +12,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -59,6 +63,16 @@ struct TwoSpan {
         return tmp.data();
     }
 };
+
+// IRF_DREADER_TRACE=1: wall-clock marks of the host side on stderr (diagnostic)
+struct Trace {
+    bool on = getenv("IRF_DREADER_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what) const {
+        if (on) fprintf(stderr, "[dreader %9.3f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+};
+const Trace g_trace;
 
 constexpr uint64_t kMinGap = 1ull << 20;    // bytes kept free in front of a slot's inflated members for the predecessor's carry
 
@@ -135,7 +149,7 @@ struct irf_dreader {
     // device side.  A feed is two stages: stage 1 (compressed bytes to the device on the copy stream, inflate + CRC on
     // the inflate stream) needs nothing from the feeds before it; stage 2 (record chain, pairing, assembly on `stream`)
     // needs the carry of its predecessor.  With the pipeline on, stage 1 of feed k runs before stage 2 of feed k - 1,
-    // so the copy of feed k + 1 and the inflate of feed k overlap.  The inflated members of a slot start at a fixed
+    // on a second host thread, so the copy of feed k + 1 overlaps the inflate of feed k and the parsing of feed k - 1.  The inflated members of a slot start at a fixed
     // offset `gap`; the carry of the predecessor is placed right in front of them.
     struct InSlot {
         DBuf<uint8_t> d_in, raw;
@@ -161,10 +175,16 @@ struct irf_dreader {
     int out_cur = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};      // stage 2: begin, chain done, assembled
 
-    int fail(int code, const std::string& msg) { err = msg; failed = true; return code; }
+    std::mutex err_mutex;                    // stage 1 and stage 2 of neighbouring feeds run on two host threads
+    int fail(int code, const std::string& msg) {
+        std::lock_guard<std::mutex> g(err_mutex);
+        if (!failed) err = msg;              // the first error stays
+        failed = true;
+        return code;
+    }
     int init();
     int feed(const uint8_t* data, size_t len);
-    int stage1(InSlot& S, const TwoSpan& in, size_t consumed_in);
+    int stage1(InSlot& S, const TwoSpan& in, size_t consumed_in, uint64_t gap);
     int stage2(InSlot& S);
     int finish();
     int host_header(const TwoSpan& in, size_t n_members_avail);
@@ -242,7 +262,9 @@ int irf_dreader::feed(const uint8_t* data, size_t len) {
     const TwoSpan in{pending.data(), pending.size(), data, len};
     zblocks.clear();
     size_t scan = 0, total_out = 0;
+    g_trace.mark("feed: begin");
     const std::string scan_error = locate_members(in, scan, total_out, zblocks);
+    g_trace.mark("feed: members located");
     if (!scan_error.empty()) return fail(IRF_E_PARSE, scan_error);
     out[out_cur ^ 1].n_frag = out[out_cur ^ 1].n_blk = 0;          // the batch of this feed: empty unless a stage 2 fills it
     bool consume = !zblocks.empty();
@@ -258,8 +280,29 @@ int irf_dreader::feed(const uint8_t* data, size_t len) {
     }
     const int cur = next_slot;
     next_slot ^= 1;
-    int rc = stage1(slot[cur], in, scan);
-    if (rc != 0) return rc;
+    // room for the predecessor's carry in front of the inflated members: the carry is known when the pipeline is off;
+    // with the pipeline on it is the one before it (stage 2 moves the members in the rare case that the carry does not fit)
+    const uint64_t gap = std::max<uint64_t>(kMinGap, (carry_len + 4095) & ~4095ull);
+    int rc = 0;
+    if (pipeline && inflight >= 0) {
+        // the copy of this feed (the calling thread is busy with it for its whole duration when the bytes are in pageable
+        // memory) next to the parsing of the feed before it
+        int rc1 = 0;
+        std::thread copier([&] {
+            rc1 = hipSetDevice(device) == hipSuccess ? stage1(slot[cur], in, scan, gap) : fail(IRF_E_DEVICE, "hipSetDevice");
+        });
+        const int prev = inflight;
+        rc = stage2(slot[prev]);
+        copier.join();
+        inflight = cur;
+        if (rc == 0) rc = rc1;
+        if (rc != 0) return rc;
+    } else {
+        rc = stage1(slot[cur], in, scan, gap);
+        if (rc != 0) return rc;
+        if (pipeline) inflight = cur;
+        else if ((rc = stage2(slot[cur])) != 0) return rc;
+    }
     // what is left behind the last complete member (stage 1 has read the caller's bytes)
     if (scan >= in.na) {
         pending.assign(data + (scan - in.na), data + len);
@@ -267,24 +310,15 @@ int irf_dreader::feed(const uint8_t* data, size_t len) {
         pending.erase(pending.begin(), pending.begin() + (ptrdiff_t)scan);
         pending.insert(pending.end(), data, data + len);
     }
-    if (pipeline) {
-        const int prev = inflight;
-        inflight = cur;
-        if (prev >= 0 && (rc = stage2(slot[prev])) != 0) return rc;
-    } else if ((rc = stage2(slot[cur])) != 0) {
-        return rc;
-    }
     out_cur ^= 1;
+    g_trace.mark("feed: end");
     return 0;
 }
 
 // Stage 1: compressed bytes + member table to the device, inflate, CRC.  Returns when the caller's bytes have been read;
 // the kernels may still be running.
-int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in) {
+int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in, uint64_t gap) {
     const uint32_t n_members = (uint32_t)zblocks.size();
-    // room for the predecessor's carry in front of the inflated members: known when the pipeline is off; with the
-    // pipeline on it is not yet (stage 2 moves the members in the rare case that the carry does not fit)
-    const uint64_t gap = std::max<uint64_t>(kMinGap, (carry_len + 4095) & ~4095ull);
     members.resize(n_members);
     uint64_t total_out = 0;
     for (uint32_t i = 0; i < n_members; i++) {
@@ -297,6 +331,7 @@ int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in) {
     MEM_TRY(S.d_status.reserve(n_members));
     MEM_TRY(S.raw.reserve(gap + total_out + 64));
     S.n_members = n_members; S.total_out = total_out; S.gap = gap; S.consumed_in = consumed_in;
+    g_trace.mark("stage1: buffers reserved");
 
     HIP_TRY(hipEventRecord(S.ev[0], s_copy));
     {
@@ -317,7 +352,9 @@ int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in) {
     HIP_TRY(hipEventRecord(S.ev[4], s_inf));
     HIP_TRY(hipGetLastError());
     // the caller's bytes (and `members`) may change once this returns, whatever kind of host memory they are in
+    g_trace.mark("stage1: launched");
     HIP_TRY(hipEventSynchronize(S.ev[1]));
+    g_trace.mark("stage1: copied");
     return 0;
 }
 
@@ -325,10 +362,12 @@ int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in) {
 int irf_dreader::stage2(InSlot& S) {
     const uint32_t n_members = S.n_members;
     uint32_t* const f_changed = d_flags.p, *const f_dangling = d_flags.p + 2;
+    g_trace.mark("stage2: begin");
     HIP_TRY(hipStreamWaitEvent(stream, S.ev[4], 0));
     uint32_t first_bad = 0;
     HIP_TRY(hipMemcpyAsync(&first_bad, S.d_first_bad.p, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    g_trace.mark("stage2: inflated");
 #ifdef IRF_INFLATE_EXP
     { float ms_ = 0; (void)hipEventElapsedTime(&ms_, S.ev[2], S.ev[3]); fprintf(stderr, "[inflate_exp %d] %u members, inflate %.3f ms\n", IRF_INFLATE_EXP, n_members, ms_); }
 #endif
@@ -390,6 +429,7 @@ int irf_dreader::stage2(InSlot& S) {
         HIP_TRY(hipStreamSynchronize(stream));
     }
     HIP_TRY(hipEventRecord(ev[1], stream));
+    g_trace.mark("stage2: chain done");
 
     // ---- records -> fragments ----
     OutSlot& O = out[out_cur ^ 1];
@@ -402,6 +442,7 @@ int irf_dreader::stage2(InSlot& S) {
     dev::AssembleArgs A;
     memset(&A, 0, sizeof A);
     if (n_rec) {
+        g_trace.mark("stage2: reserving record index");
         MEM_TRY(d_rec_off.reserve(n_rec));
         MEM_TRY(d_rec_nf.reserve(n_rec));
         MEM_TRY(d_fr.reserve((size_t)n_rec + 4));
@@ -409,6 +450,7 @@ int irf_dreader::stage2(InSlot& S) {
         MEM_TRY(d_tile_last.reserve(dev::pair_tiles(n_rec)));
         MEM_TRY(d_tile_carry.reserve(dev::pair_tiles(n_rec)));
         MEM_TRY(d_ws.reserve(dev::scan_workspace_elems((uint64_t)n_rec + 1)));
+        g_trace.mark("stage2: record index reserved");
         dev::RecordIndex R{d_rec_off.p, d_rec_nf.p, d_scal.p};
         dev::launch_chain_emit(C, d_seg_base.p, R, stream);
         dev::launch_pair_state(d_rec_nf.p, n_rec, d_tile_last.p, d_tile_carry.p, stream);
@@ -431,12 +473,14 @@ int irf_dreader::stage2(InSlot& S) {
     HIP_TRY(hipMemcpyAsync(scal, d_scal.p, sizeof scal, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
+    g_trace.mark("stage2: counted");
     if (scal[0] != ~0ull) return fail(IRF_E_PARSE, (scal[0] & 3ull) == 1ull ? "BAM: bad block_size" : "BAM: record fields overrun block_size");
     if (tail_off == dev::kNoRecord) return fail(IRF_E_DEVICE, "record chain broken without a bad record (internal error)");
 
     MEM_TRY(O.frag_chr.reserve(n_frag + 4)); MEM_TRY(O.frag_flags.reserve(n_frag + 4)); MEM_TRY(O.frag_start.reserve(n_frag + 4));
     MEM_TRY(O.frag_end.reserve(n_frag + 4)); MEM_TRY(O.frag_blk_off.reserve((size_t)n_frag + 5));
     MEM_TRY(O.blk_start.reserve(n_blk + 4)); MEM_TRY(O.blk_len.reserve(n_blk + 4)); MEM_TRY(O.blk_read.reserve(n_blk + 4));
+    g_trace.mark("stage2: out reserved");
     A.frag_chr = O.frag_chr.p; A.frag_flags = O.frag_flags.p; A.frag_start = O.frag_start.p; A.frag_end = O.frag_end.p;
     A.frag_blk_off = O.frag_blk_off.p; A.blk_start = O.blk_start.p; A.blk_len = O.blk_len.p; A.blk_read = O.blk_read.p;
     dev::launch_assemble_write(A, n_frag, n_blk, stream);
@@ -447,15 +491,18 @@ int irf_dreader::stage2(InSlot& S) {
     uint64_t tail_from = tail_off;
     if (dangling) HIP_TRY(hipMemcpyAsync(&tail_from, d_rec_off.p + (n_rec - 1), 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    g_trace.mark("stage2: written");
     const uint64_t new_carry = total - tail_from;
     if (new_carry) {
-        MEM_TRY(d_carry.reserve(new_carry + 64));
+        // (never less than the gap: growing frees the old buffer, and hipFree waits for the next feed's inflate kernel)
+        MEM_TRY(d_carry.reserve(std::max<uint64_t>(new_carry + 64, kMinGap)));
         HIP_TRY(hipMemcpyAsync(d_carry.p, raw + tail_from, new_carry, hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
     carry_len = new_carry;
     carry_dangling = dangling != 0;
     carry_partial = tail_off != total;
+    g_trace.mark("stage2: done");
 
     stats.n_records += scal[1 + dev::RS_RECORDS]; stats.n_nucleotides += scal[1 + dev::RS_NUCLEOTIDES];
     stats.n_singles += scal[1 + dev::RS_SINGLES]; stats.n_pairs += scal[1 + dev::RS_PAIRS];

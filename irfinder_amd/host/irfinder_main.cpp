@@ -12,7 +12,8 @@
 // ReadBlockProcessor-shaped adapter (hip_block_processor.h) instead of handing
 // the reader's SoA batches to the engine directly; both give identical files.
 // --device-reader: the input is BGZF and is inflated, parsed and assembled on the GPU (irf_dreader_*, SURVEY §8 f N1):
-// the host only reads stdin in --feed-mb pieces (default 256) and locates the members; same files, same summary.
+// the host only reads stdin in --feed-mb pieces (default 1024: the inflate kernel is one lane per BGZF member and needs
+// ~49 k members = 1.3 GB in flight to fill the GPU) and locates the members; same files, same summary.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,7 +98,7 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
 int main(int argc, char** argv) {
     std::vector<const char*> pos;
     bool bgzf = false, via_adapter = false, sorted_input = false, device_reader = false;
-    int device = 0, threads = 1, feed_mb = 256;
+    int device = 0, threads = 1, feed_mb = 1024;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--bgzf")) bgzf = true;
         else if (!strcmp(argv[i], "--via-adapter")) via_adapter = true;
