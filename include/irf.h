@@ -361,6 +361,13 @@ int irf_dreader_feed(irf_dreader* r, const uint8_t* bgzf, size_t len);
  * bytes passed to a feed may be reused as soon as it returns, in both modes.
  * No upstream counterpart (upstream reads a pipe synchronously).              */
 int irf_dreader_set_pipeline(irf_dreader* r, int on);
+/* BGZF members the device inflates at once (one lane per member: CUs x resident
+ * workgroups x 64; 49152 on an MI355X), 0 on error.  The inflate kernel of a
+ * feed takes about the same time for any number of members up to this and
+ * twice as long just above it, so feeds sized to a little less than a multiple
+ * of it are the efficient ones (irf_dreader_timing.n_members / bytes_in gives
+ * the members per byte seen so far).  No upstream counterpart.                */
+uint32_t irf_dreader_member_slots(const irf_dreader* r);
 int irf_dreader_header(const irf_dreader* r, const char* const** names, const uint32_t** lens);
 /* Fragments of the LAST feed (possibly none), device-resident.               */
 int irf_dreader_batch(const irf_dreader* r, irf_batch* out);

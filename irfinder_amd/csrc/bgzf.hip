@@ -589,6 +589,14 @@ void launch_bgzf_inflate(const uint8_t* in, const BgzfMember* members, uint32_t 
                        status);
 }
 
+uint32_t bgzf_inflate_slots() {
+    int dev_id = 0, cus = 0, wgs = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, bgzf_inflate_kernel, kLanes, 0) != hipSuccess || cus <= 0 || wgs <= 0)
+        return 0;
+    return (uint32_t)cus * (uint32_t)wgs * (uint32_t)kLanes;
+}
+
 void launch_bgzf_crc(const uint8_t* out, const BgzfMember* members, uint32_t n_members, uint32_t* status, hipStream_t s) {
     if (!n_members) return;
     static const CrcPowers pw = crc_powers();

@@ -596,6 +596,11 @@ int irf_dreader_set_pipeline(irf_dreader* r, int on) {
     return 0;
 }
 
+uint32_t irf_dreader_member_slots(const irf_dreader* r) {
+    if (!r || hipSetDevice(r->device) != hipSuccess) return 0;
+    return dev::bgzf_inflate_slots();
+}
+
 int irf_dreader_header(const irf_dreader* r, const char* const** names, const uint32_t** lens) {
     if (!r) return IRF_E_ARG;
     if (!r->header_done) return IRF_E_STATE;

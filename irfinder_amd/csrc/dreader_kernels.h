@@ -27,6 +27,9 @@ constexpr uint32_t kInflateSlack = 1024; // readable bytes the compressed buffer
 // status[m] = BGZF_OK / BGZF_BAD_DEFLATE.  `in` must be readable kInflateSlack bytes past the last member.
 void launch_bgzf_inflate(const uint8_t* in, const BgzfMember* members, uint32_t n_members, uint8_t* out, uint32_t* status,
                          hipStream_t s);
+// members the current device inflates at once (one lane each; CUs x resident workgroups x 64): a launch with more runs
+// in rounds of that many, and a round lasts as long as one lane needs for its member however few members it holds
+uint32_t bgzf_inflate_slots();
 // CRC-32 of every inflated member against its trailer: status[m] = BGZF_BAD_CRC where it differs (and status was OK)
 void launch_bgzf_crc(const uint8_t* out, const BgzfMember* members, uint32_t n_members, uint32_t* status, hipStream_t s);
 // first member with a non-zero status: first_bad[0] = min index (pre-set to 0xffffffff)

@@ -105,6 +105,8 @@ def lib():
     L.irf_dreader_last_error.restype = C.c_char_p
     L.irf_dreader_feed.argtypes = [vp, C.c_void_p, C.c_size_t]
     L.irf_dreader_set_pipeline.argtypes = [vp, C.c_int]
+    L.irf_dreader_member_slots.argtypes = [vp]
+    L.irf_dreader_member_slots.restype = C.c_uint32
     L.irf_dreader_header.argtypes = [vp, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(u32))]
     L.irf_dreader_batch.argtypes = [vp, C.POINTER(IrfBatch)]
     L.irf_dreader_finish.argtypes = [vp]
@@ -296,6 +298,10 @@ class DeviceReader:
 
     def finish(self):
         self._chk(self.L.irf_dreader_finish(self.h))
+
+    def member_slots(self):
+        """BGZF members the device inflates at once (irf_dreader_member_slots)."""
+        return int(self.L.irf_dreader_member_slots(self.h))
 
     def header(self):
         names = C.POINTER(C.c_char_p)()

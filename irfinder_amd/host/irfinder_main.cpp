@@ -12,8 +12,10 @@
 // ReadBlockProcessor-shaped adapter (hip_block_processor.h) instead of handing
 // the reader's SoA batches to the engine directly; both give identical files.
 // --device-reader: the input is BGZF and is inflated, parsed and assembled on the GPU (irf_dreader_*, SURVEY §8 f N1):
-// the host only reads stdin in --feed-mb pieces (default 1024: the inflate kernel is one lane per BGZF member and needs
-// ~49 k members = 1.3 GB in flight to fill the GPU) and locates the members; same files, same summary.
+// the host only reads stdin in --feed-mb pieces (default 0: sized from the members seen so far to what the device
+// inflates at once, irf_dreader_member_slots: the inflate kernel is one lane per BGZF member and needs ~49 k members
+// in flight to fill the GPU) and locates the members; same files, same summary.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +52,11 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
     // pipelined: while a piece is copied and inflated, the fragments of the piece before it are assembled and counted,
     // and stdin is read for the next one
     if (irf_dreader_set_pipeline(dr, 1) != 0) return die("irf_dreader_set_pipeline", irf_dreader_last_error(dr));
+    // feed_bytes == 0: pieces sized so that a feed holds a little less than the members the device inflates at once
+    // (the inflate kernel is one lane per member; its time does not depend on how many of its lanes are used)
+    const bool adaptive = feed_bytes == 0;
+    const uint32_t slots = irf_dreader_member_slots(dr);
+    if (adaptive) feed_bytes = (size_t)256 << 20;
     std::vector<uint8_t> buf(feed_bytes);
     bool mapped = false;
     auto take_batch = [&]() -> int {
@@ -80,6 +87,15 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
         if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
         if (irf_dreader_feed(dr, buf.data(), have) != 0) return die("BAM", irf_dreader_last_error(dr));
         if (int rc = take_batch()) return rc;
+        if (adaptive && slots) {
+            irf_dreader_timing tm;
+            if (irf_dreader_get_timing(dr, &tm) == 0 && tm.n_members > 64 && tm.bytes_in) {
+                const double per_member = (double)tm.bytes_in / (double)tm.n_members;
+                double want = 0.97 * (double)slots * per_member;
+                want = std::min(std::max(want, 64.0 * 1048576.0), 4096.0 * 1048576.0);
+                buf.resize((size_t)want);
+            }
+        }
     }
     if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
     if (irf_dreader_finish(dr) != 0) return die("BAM", irf_dreader_last_error(dr));
@@ -98,7 +114,7 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
 int main(int argc, char** argv) {
     std::vector<const char*> pos;
     bool bgzf = false, via_adapter = false, sorted_input = false, device_reader = false;
-    int device = 0, threads = 1, feed_mb = 1024;
+    int device = 0, threads = 1, feed_mb = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--bgzf")) bgzf = true;
         else if (!strcmp(argv[i], "--via-adapter")) via_adapter = true;
@@ -117,7 +133,7 @@ int main(int argc, char** argv) {
     irf_params_default(&P);
     P.mate_join = sorted_input ? 1u : 0u;
     if (device_reader) {
-        if (feed_mb < 1 || feed_mb > 16384) return die("--feed-mb", "1..16384");
+        if (feed_mb < 0 || feed_mb > 16384) return die("--feed-mb", "0 (sized by the reader) or 1..16384");
         return run_device_reader(pos, P, device, (size_t)feed_mb << 20);
     }
     irf_reader* rd = nullptr;

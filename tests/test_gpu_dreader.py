@@ -137,6 +137,7 @@ def test_device_reader_equals_host_reader_and_oracle(stranded):
     ob, ost, rc = orc.bam_to_batch(bam)
     assert rc == 0 and db.equals(ob) and ds == ost
     assert ds["n_pairs_intersect"] > 0 and ds["n_pairs_long"] > 0 and ds["n_singles"] > 0 and ds["n_pairs_short"] > 0
+    assert d.member_slots() >= 64 * 64 and d.member_slots() % 64 == 0
     t = d.timing()
     assert t["bytes_in"] == len(z) and t["bytes_inflated"] == len(bam) and t["n_members"] == (len(bam) + 0xfeff) // 0xff00 + 1
 
