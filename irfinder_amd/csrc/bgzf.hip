@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
     const uint32_t mi = blockIdx.x * kLanes + lane;
     if (mi >= n_members) return;
 #ifndef IRF_INFLATE_EXP
-#define IRF_INFLATE_EXP 0                  // diagnostic builds only (tools/inflate_exp.sh): 1 no match copies, 2 no literal stores, 4 cached input
+#define IRF_INFLATE_EXP 0                  // diagnostic builds only (tools/inflate_exp.sh): 1 no match copies, 2 no literal stores, 4 cached input, 8 no slow-path copies, 16 no deferred copies
 #endif
     BgzfMember m = members[mi];
     if (IRF_INFLATE_EXP & 4) {
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 const uint32_t whole = (len + 7u) & ~7u;
                 if (IRF_INFLATE_EXP & 1) {
                 } else if (may_overrun && whole <= 32u && dist >= whole) {
-                    dsrc = src; ddst = dst; need = whole;
+                    if (!(IRF_INFLATE_EXP & 16)) { dsrc = src; ddst = dst; need = whole; }
+                } else if (IRF_INFLATE_EXP & 8) {
                 } else {
                     if (dist >= 8) {
                         if (dist >= 32) {
