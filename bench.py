@@ -304,7 +304,7 @@ def main():
         from irfinder_amd.synth.bam import bgzf_compress_mt
         # random bases + binned qualities: compresses about as a real RNA-seq BAM does (2.4 : 1 at zlib level 6)
         sim_seq = ReadSimulator(ann, read_len=args.read_len, stranded=bool(args.stranded), seed=seed, with_seq=2)
-        n_dec = 1_000_000
+        n_dec = 4_000_000      # 0.94 GB of BGZF, 34 k members: most of the lanes of the device reader's inflate kernel (49 k) in one feed
         raw = sim_seq.bam(0, n_dec)
         z = np.frombuffer(bgzf_compress_mt(raw, 6, min(args.threads, 16)), np.uint8)
         dec = {}
@@ -343,8 +343,9 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")}, "n_members": int(tm["n_members"]),
             "same_counters_as_host_reader": dstats == host_stats, "n_frag": int(n_dev),
             "note": "irf_dreader_*: one feed of the whole file from pageable host memory (pairs_per_s includes the H2D copy and the "
-                    "host's member scan); inflate is one lane per BGZF member, so its rate grows with the members per feed up to "
-                    "~49 k (tools/bench_dreader.py --pairs 4000000: 34 k members, 95 M pairs/s in the device stages)"}
+                    "host's member scan); inflate is one lane per BGZF member and takes ~31-36 ms for any number of members up to "
+                    "irf_dreader_member_slots = 49 k, so the rate is proportional to the members per feed (1 M pairs per feed: 23 M pairs/s); "
+                    "several 1 GB feeds with irf_dreader_set_pipeline: 76 M pairs/s (profiles/r01g_dreader_pipeline.json)"}
         extra["h2d"] = {"bytes": int(in_bytes), "seconds": round(h2d_s, 4), "note": "pageable numpy -> device via torch (set-up, not timed)"}
 
     # ---------------- PCIe-inclusive rate (reported separately, never part of `value`) ----------------
