@@ -58,16 +58,21 @@ struct Bits {
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
-// The bit buffer of the symbol loop: the next two input words (q0, q1 = the 8 bytes at p) are in registers, loaded by
-// ONE unconditional load per iteration at the bottom of the loop, so a refill is register work.  An iteration refills at
-// most twice (15 + 5 bits, refill, 15 + 13 bits, refill).
+// The bit buffer of the symbol loop: the next four input words (q0 .. q3 = the 16 bytes at p, nq of them still unused)
+// are in registers, so a refill is register work.  An iteration refills at most twice (15 + 5 bits, refill, 15 + 13
+// bits, refill); at its bottom a lane with fewer than two words left reloads all four with ONE 16-byte load.  The load is
+// issued by every lane in every iteration (uniform instruction stream, see the kernel), but the lanes that do not need it
+// — about eight of nine — all read the same address: the cost of a vector memory instruction here is the number of
+// distinct cache lines it touches, not its width.
 struct FastBits {
     const uint8_t* p;    // address of q0
     uint64_t bb;
-    uint32_t bc, q0, q1;
+    uint32_t bc, q0, q1, q2, q3, nq;
     __device__ __forceinline__ void from(const Bits& s) {
-        p = s.p - 4; bb = s.bb; bc = s.bc; q0 = s.nxt; q1 = ld32u(s.p);
-        asm volatile("" ::"v"(q0), "v"(q1));      // waited for here: nothing is pending when the symbol loop is entered
+        p = s.p - 4; bb = s.bb; bc = s.bc; q0 = s.nxt;
+        q1 = ld32u(s.p); q2 = ld32u(s.p + 4); q3 = ld32u(s.p + 8);
+        nq = 4;
+        asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));      // waited for here: nothing is pending when the symbol loop is entered
     }
     __device__ __forceinline__ void to(Bits& s) const {
         s.p = p + 4; s.bb = bb; s.bc = bc; s.nxt = q0;
@@ -76,8 +81,9 @@ struct FastBits {
         if (bc <= 32) {
             bb |= (uint64_t)q0 << bc;
             bc += 32;
-            q0 = q1;
+            q0 = q1; q1 = q2; q2 = q3;
             p += 4;
+            nq--;
         }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
         return;
     }
     const uint8_t* const in0 = in + m.in_off;
-    const uint8_t* const in_lim = in0 + m.clen + 8;      // a valid stream never has its next input word beyond this (8 more bytes are read)
+    const uint8_t* const in_lim = in0 + m.clen + 8;      // a valid stream never has its next input word beyond this (16 more bytes are read)
     Bits b;
     b.start(in0);
     uint8_t* const obase = out + m.out_off;
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
         while (true) {
             if (fb.p > in_lim) { bad = true; break; }
             if (sym < 0) { bad = true; break; }
-            const uint8_t* dsrc = obase;
+            const uint8_t* dsrc = out;                      // (lanes without a deferred copy all read the same line: one tag lookup)
             uint8_t* ddst = obase;
             uint32_t need = 0;                              // bytes of a deferred copy (whole 8-byte steps)
             if (sym < 256) {
@@ -477,11 +483,16 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             uint32_t w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) w[k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(dsrc + 4 * k);
-            const uint32_t n0 = ld32u(fb.p), n1 = ld32u(fb.p + 4);
+            const bool reload = fb.nq < 2u;
+            uint4 nw;
+            __builtin_memcpy(&nw, reload ? fb.p : in, 16);
             sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
-            asm volatile("" ::"v"(n0), "v"(n1));      // the one wait: here, not at the next refill behind the stores below
-            fb.q0 = n0;
-            fb.q1 = n1;
+            asm volatile("" ::"v"(nw.x), "v"(nw.y), "v"(nw.z), "v"(nw.w));      // the one wait: here, not at the next refill behind the stores below
+            fb.q0 = reload ? nw.x : fb.q0;
+            fb.q1 = reload ? nw.y : fb.q1;
+            fb.q2 = reload ? nw.z : fb.q2;
+            fb.q3 = reload ? nw.w : fb.q3;
+            fb.nq = reload ? 4u : fb.nq;
             if (need) {
                 st32u(ddst, w[0]); st32u(ddst + 4, w[1]);
                 if (need > 8u) { st32u(ddst + 8, w[2]); st32u(ddst + 12, w[3]); }
