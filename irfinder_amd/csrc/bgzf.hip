@@ -59,8 +59,8 @@ struct Bits {
 };
 
 // The bit buffer of the symbol loop: the next four input words (q0 .. q3 = the 16 bytes at p, nq of them still unused)
-// are in registers, so a refill is register work.  An iteration refills at most twice (15 + 5 bits, refill, 15 + 13
-// bits, refill); at its bottom a lane with fewer than two words left reloads all four with ONE 16-byte load.  The load is
+// are in registers, so a refill is register work.  An iteration refills at most three times (15 + 5 bits, refill, 15 + 13
+// bits, refill, 15 bits of a literal pair, refill); at its bottom a lane with fewer than three words left reloads all four with ONE 16-byte load.  The load is
 // issued by every lane in every iteration (uniform instruction stream, see the kernel), but the lanes that do not need it
 // — about eight of nine — all read the same address: the cost of a vector memory instruction here is the number of
 // distinct cache lines it touches, not its width.
@@ -482,8 +482,11 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             fb.refill();
             uint32_t w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(dsrc + 4 * k);
-            const bool reload = fb.nq < 2u;
+            for (int k = 0; k < 4; k++) w[k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(dsrc + 4 * k);
+            const uint8_t* const hsrc = need > 16u ? dsrc + 16 : out;      // most matches are short: their upper half reads the shared line
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[4 + k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(hsrc + 4 * k);
+            const bool reload = fb.nq < 3u;                 // up to three refills until the next reload (the third: the literal pair below)
             uint4 nw;
             __builtin_memcpy(&nw, reload ? fb.p : in, 16);
             sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
@@ -499,6 +502,15 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 if (need > 16u) { st32u(ddst + 16, w[4]); st32u(ddst + 20, w[5]); }
                 if (need > 24u) { st32u(ddst + 24, w[6]); st32u(ddst + 28, w[7]); }
             }
+#ifndef IRF_NO_LITERAL_PAIR
+            // a literal needs nothing from memory: it is put at once and the symbol behind it decoded in the same
+            // iteration (the per-iteration costs — the wait, the loads every lane issues — are paid once for the pair)
+            if ((uint32_t)sym < 256u && op < isize) {
+                put((uint32_t)sym);
+                fb.refill();
+                sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
+            }
+#endif
         }
         fb.to(b);
     }
