@@ -24,6 +24,10 @@ namespace dev {
 
 namespace {
 
+#ifndef IRF_LITERAL_RUN
+#define IRF_LITERAL_RUN 1          // literals taken in the same iteration as the symbol before them (0 .. 2: the input window is four words)
+#endif
+
 constexpr int LIT_SYM = 0, DIST_SYM = 288, LIT_LIM = 320, LIT_BASE = 335, DIST_LIM = 350, DIST_BASE = 365, TAB_U16 = 380;
 constexpr int kLanes = 64;
 
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             const uint8_t* const hsrc = need > 16u ? dsrc + 16 : out;      // most matches are short: their upper half reads the shared line
 #pragma unroll
             for (int k = 0; k < 4; k++) w[4 + k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(hsrc + 4 * k);
-            const bool reload = fb.nq < 3u;                 // up to three refills until the next reload (the third: the literal pair below)
+            const bool reload = fb.nq < 2u + IRF_LITERAL_RUN;                // up to three refills until the next reload (the third: the literal pair below)
             uint4 nw;
             __builtin_memcpy(&nw, reload ? fb.p : in, 16);
             sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
@@ -502,15 +506,16 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 if (need > 16u) { st32u(ddst + 16, w[4]); st32u(ddst + 20, w[5]); }
                 if (need > 24u) { st32u(ddst + 24, w[6]); st32u(ddst + 28, w[7]); }
             }
-#ifndef IRF_NO_LITERAL_PAIR
             // a literal needs nothing from memory: it is put at once and the symbol behind it decoded in the same
             // iteration (the per-iteration costs — the wait, the loads every lane issues — are paid once for the pair)
-            if ((uint32_t)sym < 256u && op < isize) {
-                put((uint32_t)sym);
-                fb.refill();
-                sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
+#pragma unroll
+            for (int extra = 0; extra < IRF_LITERAL_RUN; extra++) {
+                if ((uint32_t)sym < 256u && op < isize) {
+                    put((uint32_t)sym);
+                    fb.refill();
+                    sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
+                }
             }
-#endif
         }
         fb.to(b);
     }
