@@ -343,9 +343,9 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")}, "n_members": int(tm["n_members"]),
             "same_counters_as_host_reader": dstats == host_stats, "n_frag": int(n_dev),
             "note": "irf_dreader_*: one feed of the whole file from pageable host memory (pairs_per_s includes the H2D copy and the "
-                    "host's member scan); inflate is one lane per BGZF member and takes ~31-36 ms for any number of members up to "
-                    "irf_dreader_member_slots = 49 k, so the rate is proportional to the members per feed (1 M pairs per feed: 23 M pairs/s); "
-                    "several 1 GB feeds with irf_dreader_set_pipeline: 76 M pairs/s (profiles/r01g_dreader_pipeline.json)"}
+                    "host's member scan); inflate is one lane per BGZF member and takes ~24-27 ms for any number of members up to "
+                    "~40 k (irf_dreader_member_slots = 49 k), so the rate is proportional to the members per feed; "
+                    "several 1 GB feeds with irf_dreader_set_pipeline: 80 M pairs/s (profiles/r01h_dreader_16m_pipeline.json)"}
         extra["h2d"] = {"bytes": int(in_bytes), "seconds": round(h2d_s, 4), "note": "pageable numpy -> device via torch (set-up, not timed)"}
 
     # ---------------- PCIe-inclusive rate (reported separately, never part of `value`) ----------------
