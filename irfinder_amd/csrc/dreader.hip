@@ -288,12 +288,18 @@ int irf_dreader::feed(const uint8_t* data, size_t len) {
         // the copy of this feed (the calling thread is busy with it for its whole duration when the bytes are in pageable
         // memory) next to the parsing of the feed before it
         int rc1 = 0;
-        std::thread copier([&] {
-            rc1 = hipSetDevice(device) == hipSuccess ? stage1(slot[cur], in, scan, gap) : fail(IRF_E_DEVICE, "hipSetDevice");
-        });
+        std::thread copier;
+        try {
+            copier = std::thread([&] {
+                rc1 = hipSetDevice(device) == hipSuccess ? stage1(slot[cur], in, scan, gap) : fail(IRF_E_DEVICE, "hipSetDevice");
+            });
+        } catch (...) {
+            // no second thread to be had: one after the other (nothing may be thrown across the C ABI)
+        }
         const int prev = inflight;
         rc = stage2(slot[prev]);
-        copier.join();
+        if (copier.joinable()) copier.join();
+        else rc1 = stage1(slot[cur], in, scan, gap);
         inflight = cur;
         if (rc == 0) rc = rc1;
         if (rc != 0) return rc;
