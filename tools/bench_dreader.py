@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--host-threads", type=int, default=16)
+    ap.add_argument("--pinned", type=int, default=0, help="1: the compressed bytes are fed from page-locked host memory")
     ap.add_argument("--pipeline", type=int, default=0, help="1: irf_dreader_set_pipeline (copy of a piece overlaps the inflate of the one before)")
     args = ap.parse_args()
     ann = make_annotation(small_chroms(4, 20_000_000), seed=9)
@@ -33,8 +34,11 @@ def main():
     print("[bench_dreader] %d pairs, %.1f MB BAM, %.1f MB BGZF (level %d), made in %.1fs" % (
         args.pairs, len(raw) / 1e6, len(z) / 1e6, args.level, time.perf_counter() - t0), file=sys.stderr, flush=True)
     zb = np.frombuffer(z, np.uint8)
+    if args.pinned:
+        import torch
+        zb = torch.from_numpy(zb.copy()).pin_memory().numpy()
     piece = args.piece << 20 if args.piece else len(z)
-    out = {"pairs": args.pairs, "bam_MB": round(len(raw) / 1e6, 1), "bgzf_MB": round(len(z) / 1e6, 1), "level": args.level, "pipeline": args.pipeline,
+    out = {"pairs": args.pairs, "bam_MB": round(len(raw) / 1e6, 1), "bgzf_MB": round(len(z) / 1e6, 1), "level": args.level, "pipeline": args.pipeline, "pinned_input": args.pinned,
            "piece_MB": args.piece or round(len(z) / 1e6, 1)}
     best = None
     for rep in range(args.reps):
