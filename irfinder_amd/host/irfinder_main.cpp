@@ -15,6 +15,10 @@
 // the host only reads stdin in --feed-mb pieces (default 0: sized from the members seen so far to what the device
 // inflates at once, irf_dreader_member_slots: the inflate kernel is one lane per BGZF member and needs ~49 k members
 // in flight to fill the GPU) and locates the members; same files, same summary.
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -57,7 +61,6 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
     const bool adaptive = feed_bytes == 0;
     const uint32_t slots = irf_dreader_member_slots(dr);
     if (adaptive) feed_bytes = (size_t)256 << 20;
-    std::vector<uint8_t> buf(feed_bytes);
     bool mapped = false;
     auto take_batch = [&]() -> int {
         if (!mapped) {
@@ -78,14 +81,41 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
         }
         return 0;
     };
+    // stdin redirected from a regular file: the pieces are fed straight from a mapping of the file (no read() copy)
+    const uint8_t* map = nullptr;
+    size_t map_len = 0, map_pos = 0;
+    {
+        struct stat st;
+        if (fstat(0, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            const off_t at = lseek(0, 0, SEEK_CUR);
+            if (at >= 0 && at < st.st_size) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, 0, 0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    map = static_cast<const uint8_t*>(m); map_len = (size_t)st.st_size; map_pos = (size_t)at;
+                }
+            }
+        }
+    }
+    size_t piece = feed_bytes;
+    std::vector<uint8_t> buf(map ? 0 : piece);
     while (true) {
+        const uint8_t* data = nullptr;
         size_t have = 0, n;
-        while (have < buf.size() && (n = fread(buf.data() + have, 1, buf.size() - have, stdin)) > 0) have += n;
+        if (map) {
+            data = map + map_pos;
+            have = std::min(piece, map_len - map_pos);
+            map_pos += have;
+        } else {
+            if (buf.size() != piece) buf.resize(piece);
+            while (have < buf.size() && (n = fread(buf.data() + have, 1, buf.size() - have, stdin)) > 0) have += n;
+            data = buf.data();
+        }
         if (!have) break;
         // the batch submitted last lives in one of the reader's two slots: this feed fills the other one, so the
         // count kernel of that batch must have finished only before the feed after this one
         if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
-        if (irf_dreader_feed(dr, buf.data(), have) != 0) return die("BAM", irf_dreader_last_error(dr));
+        if (irf_dreader_feed(dr, data, have) != 0) return die("BAM", irf_dreader_last_error(dr));
         if (int rc = take_batch()) return rc;
         if (adaptive && slots) {
             irf_dreader_timing tm;
@@ -93,10 +123,11 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
                 const double per_member = (double)tm.bytes_in / (double)tm.n_members;
                 double want = 0.97 * (double)slots * per_member;
                 want = std::min(std::max(want, 64.0 * 1048576.0), 4096.0 * 1048576.0);
-                buf.resize((size_t)want);
+                piece = (size_t)want;
             }
         }
     }
+    if (map) (void)munmap(const_cast<uint8_t*>(map), map_len);
     if (irf_sync(ctx) != 0) return die("irf_sync", irf_last_error(ctx));
     if (irf_dreader_finish(dr) != 0) return die("BAM", irf_dreader_last_error(dr));
     if (int rc = take_batch()) return rc;

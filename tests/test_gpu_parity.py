@@ -279,11 +279,15 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     exe = os.path.join(root, "irfinder_amd", "irfinder_hip")
     for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam"),
                             ("sorted", ["--bgzf", "--sorted", "--threads", "4"], "sorted.bam"),
-                            ("device-reader", ["--device-reader"], "in.bam"), ("device-reader-1mb", ["--device-reader", "--feed-mb", "1"], "in.bam")):
+                            ("device-reader", ["--device-reader"], "in.bam"), ("device-reader-1mb", ["--device-reader", "--feed-mb", "1"], "in.bam"),
+                            ("device-reader-pipe", ["--device-reader"], "in.bam")):
         out = tmp_path / tag
         out.mkdir()
-        with open(tmp_path / src, "rb") as fh:
-            p = subprocess.run([exe, str(out)] + refs + extra, stdin=fh, capture_output=True, timeout=120)
+        if tag.endswith("-pipe"):      # stdin is a pipe (read in pieces); the other device-reader runs map the file
+            p = subprocess.run([exe, str(out)] + refs + extra, input=(tmp_path / src).read_bytes(), capture_output=True, timeout=120)
+        else:
+            with open(tmp_path / src, "rb") as fh:
+                p = subprocess.run([exe, str(out)] + refs + extra, stdin=fh, capture_output=True, timeout=120)
         assert p.returncode == 0, (tag, p.stderr)
         assert p.stdout == cpu_stdout, tag                       # reader summary
         files = sorted(os.listdir(cpu))
