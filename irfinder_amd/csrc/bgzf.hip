@@ -339,17 +339,20 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
     auto put = [&](uint32_t byte) {
         uint8_t* a = obase + op;
         if (IRF_INFLATE_EXP & 2) { op++; return; }
-        if (pn == 0 && (reinterpret_cast<uintptr_t>(a) & 3u)) {
-            *a = (uint8_t)byte;
-        } else {
-            pend |= byte << (8 * pn);
-            if (++pn == 4) {
-                *reinterpret_cast<uint32_t*>(a - 3) = pend;
-                pend = 0;
-                pn = 0;
-            }
+        pend |= byte << (8 * pn);
+        if (++pn == 4) {
+            st32u(a - 3, pend);                 // (any alignment)
+            pend = 0;
+            pn = 0;
         }
         op++;
+    };
+    // in front of a match of >= 3 bytes that fits the member: the pending literals leave as ONE dword; the zero bytes
+    // behind them lie inside the match's destination, which is written afterwards
+    auto flush_before_match = [&]() {
+        if (pn) st32u(obase + op - pn, pend);
+        pend = 0;
+        pn = 0;
     };
     auto flush = [&]() {
         uint8_t* a = obase + op - pn;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                     dist = 1u + ((2u + ((uint32_t)ds & 1u)) << e) + fb.take(e);
                 }
                 if (dist > op || op + len > isize) { bad = true; break; }
-                flush();
+                flush_before_match();
                 uint8_t* dst = obase + op;
                 const uint8_t* src = dst - dist;
                 // Whole 8-byte steps may write up to 8 bytes past the end of the match as long as they stay inside the
