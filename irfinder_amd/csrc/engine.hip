@@ -204,11 +204,16 @@ int alloc_zero(irf_ctx* c, DevBuf<T>& buf, size_t n) {
 
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 
-// tuning knob read from the environment (diagnostic; the defaults are the shipped configuration)
+// Diagnostic switches (kernel ablations, tuning knobs) exist only in builds with -DIRF_DIAG (tools/build_variant.sh):
+// the shipped library never reads the environment on the counting path, so a stray variable cannot change a table.
+#ifdef IRF_DIAG
 uint64_t env_u64(const char* name, uint64_t dflt) {
     const char* v = getenv(name);
     return v && *v ? strtoull(v, nullptr, 10) : dflt;
 }
+#else
+inline uint64_t env_u64(const char*, uint64_t dflt) { return dflt; }
+#endif
 
 }   // namespace
 
@@ -628,7 +633,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.sp_min_len = P.sp_overhang_left + P.sp_overhang_right;
     T.sp_lo_add = P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u);
     T.sp_hi_sub = P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u);
-    { const char* ab = getenv("IRF_ABLATE"); T.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
+    T.ablate = (uint32_t)env_u64("IRF_ABLATE", 0);          // 0 unless built with -DIRF_DIAG
     T.plane_stride = plane_stride; T.full_size = full_size; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
     T.junc_capacity = d_junc_a.cap;
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
@@ -757,7 +762,7 @@ void irf_ctx::launch_stats(int t, int dirn) {
     T.n_ustart = n_us; T.n_uend = n_ue;
     T.ukeys = d_ukeys.p; T.ucount = d_ucount.p; T.n_unique = n_unique;
     T.known_cnt = d_known_cnt.p; T.n_kj = n_kj;
-    { const char* ab = getenv("IRF_ABLATE_STATS"); T.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
+    T.ablate = (uint32_t)env_u64("IRF_ABLATE_STATS", 0);    // 0 unless built with -DIRF_DIAG
     T.trim_centre_pct = P.trim_centre_pct; T.pct_interpolate = P.pct_interpolate;
     T.flank_offset = P.flank_offset; T.flank_len = P.flank_len; T.flank_use_measured = P.flank_use_measured;
     T.directionality = dirn;
@@ -778,7 +783,7 @@ int irf_ctx::finalize() {
     // (exclusive scan of the per-segment sums the count kernel kept next to the planes) and the known-junction
     // lookups with the strandedness vote (known junctions were counted in place; novel ones never vote).
     dev::launch_known_junction_depth(count_tables(), stream);
-    if (getenv("IRF_RESCAN_PLANES")) dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_seg_sum.p, stream);     // diagnostic: recompute the sums from the planes
+    if (env_u64("IRF_RESCAN_PLANES", 0)) dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_seg_sum.p, stream);     // diagnostic: recompute the sums from the planes
     dev::launch_exclusive_scan_u32(d_seg_sum.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[1], stream));
     if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));

@@ -207,6 +207,23 @@ def test_empty_and_reset():
     assert_results_equal(e.results(), c, rel=0.0, what="second sample")
 
 
+def test_diagnostic_environment_switches_do_not_reach_the_product(monkeypatch):
+    """IRF_ABLATE / IRF_ABLATE_STATS / IRF_RESCAN_PLANES / IRF_STATS_* exist only in -DIRF_DIAG builds
+    (tools/build_variant.sh): with them set, the shipped library still gives the oracle's tables."""
+    for k, v in (("IRF_ABLATE", "127"), ("IRF_ABLATE_STATS", "3"), ("IRF_RESCAN_PLANES", "1"), ("IRF_STATS_SMALL_MAX", "1"),
+                 ("IRF_STATS_WGS_BIG", "1"), ("IRF_STATS_WGS_SMALL", "1")):
+        monkeypatch.setenv(k, v)
+    ann, sim = small_world(seed=5)
+    names, lens, batch = read_batch(sim.bam(0, 4000))
+    ref = engine.RefTables.from_texts(ann.ref_texts())
+    e = engine.Engine(ref)
+    e.chr_map_update(names, lens)
+    e.process(batch)
+    e.finalize()
+    o, c = run_orc(ann.ref_texts(), names, lens, [batch])
+    assert_results_equal(e.results(), c, rel=0.0, what="with diagnostic variables set")
+
+
 def test_bad_input_is_reported_not_counted():
     ann, sim = small_world(seed=2)
     names, lens, batch = read_batch(sim.bam(0, 100))
