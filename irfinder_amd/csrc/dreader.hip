@@ -556,6 +556,27 @@ int irf_dreader::finish() {
     return 0;
 }
 
+// ---- irf_gpu_bgzf_inflate_noalloc: device scratch that exists without any allocation call ----------------------------
+// A file-scope device array: every GPU the library runs on holds its own copy (9 MiB) until the process ends.  Layout:
+// [compressed bytes + kInflateSlack | member table | status words + first-bad word].
+namespace {
+constexpr int kNaMaxDevices = 64;
+constexpr size_t kNaInOff = 0;
+constexpr size_t kNaMemOff = ((size_t)IRF_NOALLOC_MAX_BYTES + dev::kInflateSlack + 255) / 256 * 256;
+constexpr size_t kNaStatusOff = kNaMemOff + (size_t)IRF_NOALLOC_MAX_MEMBERS * sizeof(dev::BgzfMember);
+constexpr size_t kNaBytes = (kNaStatusOff + ((size_t)IRF_NOALLOC_MAX_MEMBERS + 1) * sizeof(uint32_t) + 255) / 256 * 256;
+static_assert(kNaStatusOff % 256 == 0, "scratch sections stay aligned");
+}   // namespace
+static __device__ __align__(256) uint8_t na_scratch[kNaBytes];
+namespace {
+struct NaDevice {
+    std::mutex mu;
+    uint8_t* scratch = nullptr;                            // hipGetSymbolAddress(na_scratch) with this device current
+    dev::BgzfMember mem[IRF_NOALLOC_MAX_MEMBERS];          // host copy of the member table
+};
+NaDevice g_na[kNaMaxDevices];
+}   // namespace
+
 extern "C" {
 
 int irf_dreader_create(const irf_params* params, int device, irf_dreader** out) {
@@ -680,5 +701,60 @@ int irf_gpu_bgzf_inflate(int device, const uint8_t* bgzf, size_t len, uint8_t* o
     if (hipMemcpy(out, d_out.p, total_out, hipMemcpyDeviceToHost) != hipSuccess) return IRF_E_DEVICE;
     return 0;
 }
+
+int irf_gpu_bgzf_inflate_noalloc(int device, const uint8_t* bgzf, size_t len, uint8_t* out_device, size_t out_cap, size_t* out_len) {
+    if ((!bgzf && len) || !out_len) return IRF_E_ARG;
+    *out_len = 0;
+    if (device < 0 || device >= kNaMaxDevices) return IRF_E_ARG;
+    if (len > IRF_NOALLOC_MAX_BYTES) return IRF_E_RANGE;          // beyond the scratch array's staging area
+    if (hipSetDevice(device) != hipSuccess) return IRF_E_DEVICE;
+    NaDevice& D = g_na[device];
+    std::lock_guard<std::mutex> lock(D.mu);                       // (host state only: calls that overlap on one GPU still share the array)
+    if (!D.scratch) {
+        // this device's copy of the array; the name `na_scratch` itself is only a host-side handle
+        uint8_t* ptr = nullptr;
+        if (hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(na_scratch)) != hipSuccess || !ptr) return IRF_E_DEVICE;
+        D.scratch = ptr;
+    }
+    // member table (host: a fixed per-device array)
+    uint32_t n = 0;
+    size_t scan = 0, total_out = 0;
+    while (true) {
+        irf::ZBlock b;
+        size_t member_bytes = 0;
+        const char* what = "";
+        const int rc = irf::bgzf_next_member(bgzf, len, scan, total_out, b, member_bytes, &what);
+        if (rc < 0) return IRF_E_PARSE;
+        if (rc == 0) break;
+        if (n == IRF_NOALLOC_MAX_MEMBERS) return IRF_E_RANGE;
+        D.mem[n++] = dev::BgzfMember{b.in_off, b.out_off, (uint32_t)b.clen, b.isize, b.crc, 0};
+        total_out += b.isize;
+        scan += member_bytes;
+    }
+    if (scan != len) return IRF_E_PARSE;
+    *out_len = total_out;
+    if (total_out + 64 > out_cap) return IRF_E_RANGE;
+    if (total_out == 0) return 0;
+    if (!out_device) return IRF_E_ARG;
+    uint8_t* const d_in = D.scratch + kNaInOff;
+    dev::BgzfMember* const d_mem = reinterpret_cast<dev::BgzfMember*>(D.scratch + kNaMemOff);
+    uint32_t* const d_status = reinterpret_cast<uint32_t*>(D.scratch + kNaStatusOff);
+    // everything the kernels read from the array is written here first (it keeps the last call's contents)
+    bool ok = hipMemcpy(d_in, bgzf, len, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(d_in + len, 0, dev::kInflateSlack) == hipSuccess;
+    ok = ok && hipMemcpy(d_mem, D.mem, sizeof(dev::BgzfMember) * n, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(d_status, 0, sizeof(uint32_t) * n) == hipSuccess;
+    ok = ok && hipMemset(d_status + n, 0xff, 4) == hipSuccess;
+    if (!ok) return IRF_E_DEVICE;
+    dev::launch_bgzf_inflate(d_in, d_mem, n, out_device, d_status, nullptr);
+    dev::launch_bgzf_crc(out_device, d_mem, n, d_status, nullptr);
+    dev::launch_first_bad(d_status, n, d_status + n, nullptr);
+    if (hipGetLastError() != hipSuccess) return IRF_E_DEVICE;
+    uint32_t first_bad = 0;
+    if (hipMemcpy(&first_bad, d_status + n, 4, hipMemcpyDeviceToHost) != hipSuccess) return IRF_E_DEVICE;
+    if (first_bad != 0xffffffffu) return IRF_E_PARSE;
+    return 0;
+}
+
 
 }   // extern "C"

@@ -114,6 +114,7 @@ def lib():
     L.irf_dreader_get_timing.argtypes = [vp, C.POINTER(IrfDreaderTiming)]
     L.irf_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.irf_gpu_bgzf_inflate.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.irf_gpu_bgzf_inflate_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _LIB = L
     return L
 
@@ -271,6 +272,22 @@ def gpu_bgzf_inflate(data, device=0):
         if rc != 0:
             raise IrfError(rc, "irf_gpu_bgzf_inflate")
     return out
+
+
+NOALLOC_MAX_BYTES = 8 << 20       # include/irf.h: IRF_NOALLOC_MAX_BYTES / IRF_NOALLOC_MAX_MEMBERS
+NOALLOC_MAX_MEMBERS = 8192
+
+
+def gpu_bgzf_inflate_noalloc(data, out_device_ptr, out_cap, device=0):
+    """irf_gpu_bgzf_inflate_noalloc: whole BGZF members (host) -> inflated bytes in CALLER-owned device memory
+    (out_cap >= inflated size + 64); allocates nothing.  Returns the inflated size."""
+    L = lib()
+    ptr, n, keep = _buf(data)
+    need = C.c_size_t()
+    rc = L.irf_gpu_bgzf_inflate_noalloc(int(device), ptr, n, C.c_void_p(out_device_ptr), int(out_cap), C.byref(need))
+    if rc != 0:
+        raise IrfError(rc, "irf_gpu_bgzf_inflate_noalloc (needs %d bytes)" % need.value)
+    return need.value
 
 
 class DeviceReader:

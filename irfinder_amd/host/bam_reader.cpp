@@ -130,33 +130,43 @@ int BamReader::feed(const uint8_t* data, size_t len, bool bgzf) {
 // BGZF (SAM spec §4.1): gzip members with a 'BC' extra subfield carrying BSIZE.  The complete members in the buffer are
 // located first (their inflated sizes are in the trailers, so every member knows where its output goes), then
 // inflated and CRC-checked independently — by the worker pool when there is one.
+int bgzf_next_member(const uint8_t* buf, size_t size, size_t scan, size_t total_out, ZBlock& b, size_t& member_bytes, const char** what) {
+    const size_t avail = size - scan;
+    if (avail < 18) return 0;
+    const uint8_t* h = buf + scan;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { *what = "BGZF: bad member header"; return -1; }
+    const uint32_t xlen = le16(h + 10);
+    if (avail < 12 + (size_t)xlen) return 0;
+    uint32_t bsize = 0;
+    bool found = false;
+    for (uint32_t x = 0; x + 4 <= xlen;) {
+        const uint8_t* sf = h + 12 + x;
+        const uint32_t slen = le16(sf + 2);
+        if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = le16(sf + 4); found = true; }
+        x += 4 + slen;
+    }
+    if (!found) { *what = "BGZF: missing BC subfield"; return -1; }
+    const size_t total = (size_t)bsize + 1;
+    if (total < 12 + (size_t)xlen + 8) { *what = "BGZF: bad BSIZE"; return -1; }
+    if (avail < total) return 0;
+    b.in_off = scan + 12 + xlen;
+    b.clen = total - 12 - xlen - 8;
+    b.crc = le32(h + total - 8);
+    b.isize = le32(h + total - 4);
+    if (b.isize > 65536) { *what = "BGZF: ISIZE > 64 KiB"; return -1; }
+    b.out_off = total_out;
+    member_bytes = total;
+    return 1;
+}
+
 std::string bgzf_locate(const uint8_t* buf, size_t size, size_t& scan, size_t& total_out, std::vector<ZBlock>& out) {
     while (true) {
-        size_t avail = size - scan;
-        if (avail < 18) break;
-        const uint8_t* h = buf + scan;
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return "BGZF: bad member header";
-        uint32_t xlen = le16(h + 10);
-        if (avail < 12 + (size_t)xlen) break;
-        uint32_t bsize = 0;
-        bool found = false;
-        for (uint32_t x = 0; x + 4 <= xlen;) {
-            const uint8_t* sf = h + 12 + x;
-            uint32_t slen = le16(sf + 2);
-            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = le16(sf + 4); found = true; }
-            x += 4 + slen;
-        }
-        if (!found) return "BGZF: missing BC subfield";
-        size_t total = (size_t)bsize + 1;
-        if (total < 12 + (size_t)xlen + 8) return "BGZF: bad BSIZE";
-        if (avail < total) break;
         ZBlock b;
-        b.in_off = scan + 12 + xlen;
-        b.clen = total - 12 - xlen - 8;
-        b.crc = le32(h + total - 8);
-        b.isize = le32(h + total - 4);
-        if (b.isize > 65536) return "BGZF: ISIZE > 64 KiB";
-        b.out_off = total_out;
+        size_t total = 0;
+        const char* what = "";
+        const int rc = bgzf_next_member(buf, size, scan, total_out, b, total, &what);
+        if (rc < 0) return what;
+        if (rc == 0) break;
         total_out += b.isize;
         out.push_back(b);
         scan += total;

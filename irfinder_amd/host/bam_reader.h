@@ -27,6 +27,9 @@ uint32_t cigar_to_blocks(uint32_t pos, const uint32_t* cigar, uint32_t n_cigar, 
 
 // One complete BGZF member inside a buffer: where its DEFLATE data is, where its inflated bytes go
 struct ZBlock { size_t in_off, clen, out_off; uint32_t isize, crc; };
+// One step of bgzf_locate, without allocation: the member at buf + scan.  1 = complete (b filled, out_off = total_out,
+// member_bytes = its size in the compressed stream), 0 = not complete yet, -1 = malformed (*what says why).
+int bgzf_next_member(const uint8_t* buf, size_t size, size_t scan, size_t total_out, ZBlock& b, size_t& member_bytes, const char** what);
 // Locates the complete BGZF members of buf[scan, size): appends them to out (out_off continues from total_out), moves
 // scan behind the last complete member.  Returns the empty string, or what is wrong with the member at scan.
 std::string bgzf_locate(const uint8_t* buf, size_t size, size_t& scan, size_t& total_out, std::vector<ZBlock>& out);
