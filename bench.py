@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--stranded", type=int, default=0)
     ap.add_argument("--order", choices=["sorted", "random"], default="sorted")
     ap.add_argument("--genome", choices=["grch38", "chr22", "toy"], default="grch38")
+    ap.add_argument("--novel-frac", type=float, default=0.10,
+                    help="fraction of the ref-sj.ref rows withheld from the engine: reads over them are novel junctions (radix sort-reduce path)")
+    ap.add_argument("--no-random-leg", action="store_true", help="skip the reported collated-order (unsorted) leg")
     ap.add_argument("--cpu-pairs", type=int, default=50_000_000, help="size of the CPU-baseline sample (0 = skip); the default is the whole workload: about 10-20 s on one core")
     ap.add_argument("--threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "8")))
     ap.add_argument("--no-decode-bench", action="store_true")
@@ -111,7 +114,10 @@ def main():
     gen_s = time.time() - t0
     host = synth_world.concat_batches(batches)
     del batches
+    host_collated = None
     if args.order == "sorted":
+        if world == 1 and not args.no_random_leg:
+            host_collated = host                 # generation order = what a name-collated BAM (and the device reader) hands over
         host = synth_world.sort_by_coordinate(host)
     n_frag, n_blk = host.n_frag, host.n_blk
     log("rank %d: %d fragments, %d blocks (%.2f/frag) generated+assembled in %.1fs (%.2f M pairs/s host, %d threads); "
@@ -125,7 +131,10 @@ def main():
     in_bytes = sum(getattr(host, n).nbytes for n, _ in Batch.FIELDS)
     dbatch = engine.device_batch(dten, n_frag, n_blk)
 
-    ref = engine.RefTables.from_texts(ann.ref_texts())
+    # the engine's view of the annotation: a stated fraction of ref-sj.ref is withheld, so those junctions are novel
+    texts = ann.ref_texts(hide_sj_frac=args.novel_frac, hide_seed=seed)
+    n_sj_shown = texts[1].count("\n")
+    ref = engine.RefTables.from_texts(texts)
     eng = engine.Engine(ref, device=local_rank)
     eng.chr_map_update(names, lens, owned if world > 1 else None)
 
@@ -204,6 +213,7 @@ def main():
         phase[k] = 0.0
     t0 = time.perf_counter()
     kt = {"count_ms": 0.0, "scan_ms": 0.0, "stats_ms": 0.0, "junction_ms": 0.0}
+    tm = {}
     for _ in range(args.steps):
         step()
         tm = eng.timing()
@@ -244,7 +254,16 @@ def main():
     achieved = alg[dom] / (kt[dom] * 1e-3) / 1e9 if kt[dom] > 0 else 0.0
     kernels = {k: {"ms": round(kt[k], 4), "alg_bytes": int(alg[k]), "GBps": round(alg[k] / (kt[k] * 1e-3) / 1e9, 1) if kt[k] > 0 else None}
                for k in alg}
-    kernels["junction_ms"] = {"ms": round(kt["junction_ms"], 4)}
+    # novel junctions: event buffer written by the count kernel (8 B), key-bits pass (read), per radix pass histogram read
+    # + scatter read + write, head flags + compaction reads; known-junction lookups ride in the same interval
+    # (a record = 8-byte key + 4-byte weight: the count kernel merges a chunk's events on one junction before appending)
+    j_rec, j_passes = int(tm.get("n_sort_records", 0)), int(tm.get("n_radix_passes", 0))
+    j_novel = sum(int(c.to(torch.int64).sum().item()) for c in out["got"]["junc_counts"])
+    out["novel_events"] = j_novel
+    alg_j = j_rec * 12 * (1 + 3 * j_passes + 2)
+    kernels["junction_ms"] = {"ms": round(kt["junction_ms"], 4), "alg_bytes": int(alg_j), "novel_events": j_novel, "sort_records": j_rec, "radix_passes": j_passes,
+                              "GBps": round(alg_j / (kt["junction_ms"] * 1e-3) / 1e9, 1) if kt["junction_ms"] > 0 else None,
+                              "note": "radix sort-reduce of the novel-junction events (+ known-junction lookups and the vote); latency-bound at this size"}
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command (profiles/README.md);
     # bench.py itself cannot collect hardware counters
     traffic = None
@@ -277,7 +296,7 @@ def main():
                 break
         sel = np.nonzero(np.isin(host.frag_chr, keep))[0]
         sample = host.select(sel)
-        refs_s = synth_world.restrict_refs(ann.ref_texts(), [names[c] for c in keep])
+        refs_s = synth_world.restrict_refs(texts, [names[c] for c in keep])
         o = orc.Oracle(refs_s)
         o.chr_map_update(names, lens)
         t0 = time.perf_counter()
@@ -291,13 +310,63 @@ def main():
                          "count %.2fs + finalize %.2fs; CPU restatement of IRFinder semantics, not the upstream binary" % (
                              "every chromosome = the whole workload" if len(keep) == int((counts > 0).sum()) else ",".join(names[c] for c in keep),
                              sample.n_frag, t1 - t0, t2 - t1)}
-        # cross-check: the GPU rows of those chromosomes equal the oracle's (same sample => same rows)
+        # cross-check: EVERY column of the GPU's IR rows on those chromosomes equals the oracle's, bit for bit (same sample
+        # => same rows); when the sample is the whole workload also the junction table, SpansPoint, ROI and chromosome counts
+        from irfinder_amd._abi import IR_F64, IR_U32
+        gres = eng.results()
         rows = np.nonzero(np.isin(in_chr, keep))[0]
-        g_depth = out["ir_f64"][1].numpy()[rows]
-        in_chr_s = [i for i, l in enumerate(ann.cover_bed.splitlines()) if name_to_idx[l.split("\t", 1)[0]] in keep]
-        c_depth = cres["nondir"]["intron_depth"]
-        extra["sample_rows_match_oracle"] = bool(len(c_depth) == len(g_depth) and np.array_equal(np.asarray(c_depth), g_depth))
+        whole = len(keep) == int((counts > 0).sum()) and len(rows) == n_in
+        diff = []
+        for tname in ("nondir", "dir"):
+            if gres["has_dir"] != cres["has_dir"]:
+                diff.append("has_dir")
+                break
+            if tname == "dir" and not gres["has_dir"]:
+                continue
+            for k in IR_F64 + IR_U32 + ("warning",):
+                g_col, c_col = np.asarray(gres[tname][k])[rows], np.asarray(cres[tname][k])
+                if len(g_col) != len(c_col) or not np.array_equal(g_col, c_col):
+                    diff.append("%s.%s" % (tname, k))
+        compared = ["%d IR rows x %d columns" % (len(rows), len(IR_F64) + len(IR_U32) + 1)]
+        if whole:
+            for k in ("directionality", "n_fragments", "n_blocks", "n_junction_events"):
+                if gres[k] != cres[k]:
+                    diff.append(k)
+            for k in ("chr_cnt", "roi_cnt", "sp_chr", "sp_pos", "sp_cnt", "junc_chr", "junc_left", "junc_right", "junc_cnt", "junc_refdir"):
+                if gres[k].shape != cres[k].shape or not np.array_equal(gres[k], cres[k]):
+                    diff.append(k)
+            compared.append("junction table (%d rows), SpansPoint, ROI, chromosome counts" % len(gres["junc_left"]))
+        extra["sample_rows_match_oracle"] = not diff
+        extra["oracle_check"] = {"compared": compared, "differing": diff}
         o.close()
+
+    # ---------------- the same sample in collated (generation) order: what --device-reader feeds (reported, never `value`) ----------------
+    if host_collated is not None:
+        dten_c = {n: torch.from_numpy(getattr(host_collated, n)).to(dev) for n, _ in Batch.FIELDS}
+        dbatch_c = engine.device_batch(dten_c, host_collated.n_frag, host_collated.n_blk)
+        n_rep = max(1, min(args.steps, 5))
+        c_ms = 0.0
+        for rep in range(n_rep + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.reset()
+            eng.submit(dbatch_c)
+            eng.finalize()
+            t_ir = export(COL_IR_NONDIR_F64, (8, n_in), torch.float64)
+            out["ir_f64"].copy_(t_ir, non_blocking=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if rep:          # first pass = warm-up
+                c_ms += eng.timing()["count_ms"]
+                best_c = t1 - t0 if rep == 1 else min(best_c, t1 - t0)
+        same = bool(np.array_equal(out["ir_f64"].numpy(), out["got"]["ir_f64"].cpu().numpy()))
+        extra["order_random"] = {"ms_per_step": round(best_c * 1e3, 3), "pairs_per_s": round(args.pairs / best_c, 1),
+                                 "count_ms": round(c_ms / n_rep, 4),
+                                 "count_GBps": round(alg["count_ms"] / (c_ms / n_rep * 1e-3) / 1e9, 1) if c_ms > 0 else None,
+                                 "same_rows_as_sorted_run": same,
+                                 "note": "the same fragments in name-collated (generation) order, device-resident: the order irf_dreader_* "
+                                         "delivers; the count kernel's LDS difference window is built for coordinate-sorted input"}
+        del dten_c, dbatch_c
 
     # ---------------- host decode bound (reported separately, never part of `value`) ----------------
     if world == 1 and not args.no_decode_bench:
@@ -413,9 +482,11 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%d M simulated 2x%dbp pairs per GPU, %s synthetic GENCODE-like reference (%d introns), %s, %s order%s" % (
             args.pairs // 1_000_000, args.read_len, {"grch38": "full GRCh38-sized", "chr22": "chr22-only", "toy": "toy"}[args.genome],
-            ann.n_intron, "stranded" if args.stranded else "unstranded", args.order,
+            ann.n_intron, "stranded" if args.stranded else "unstranded", args.order + (
+                ", %.0f %% of ref-sj.ref withheld from the engine (novel junctions)" % (100 * args.novel_frac) if args.novel_frac > 0 else ""),
             ", chromosome-sharded over %d GPUs with RCCL collection of the tables" % world if world > 1 else ""),
-            "fragments_per_gpu": n_frag, "blocks_per_gpu": n_blk, "novel_junction_rows": out.get("n_junc"), "reads_on_known_junctions": out.get("known_reads"),
+            "fragments_per_gpu": n_frag, "blocks_per_gpu": n_blk, "novel_junction_rows": out.get("n_junc"), "novel_junction_events": out.get("novel_events"),
+            "reads_on_known_junctions": out.get("known_reads"), "ref_sj_rows_shown": n_sj_shown, "ref_sj_rows_total": ann.n_junction,
             "parallelism": "chromosome shards x%d" % world},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -272,7 +272,9 @@ typedef struct irf_timing {
     float table_ms;
     float total_finalize_ms;
     uint32_t n_count_launches;
-    uint32_t reserved;
+    uint32_t n_radix_passes;   /* 8-bit digit passes the novel-junction sort ran (digits equal in every key are skipped) */
+    uint64_t n_sort_records;   /* (key, weight) records the novel-junction radix sort-reduce ran over (the count kernel
+                                  merges a chunk's events on one junction before it appends them)                        */
 } irf_timing;
 int irf_get_timing(irf_ctx* ctx, irf_timing* out);
 

@@ -117,7 +117,7 @@ class IrfLayout(C.Structure):
 class IrfTiming(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("count_ms", "scan_ms", "stats_ms", "junction_ms", "table_ms",
                                          "total_finalize_ms")] + \
-               [("n_count_launches", C.c_uint32), ("reserved", C.c_uint32)]
+               [("n_count_launches", C.c_uint32), ("n_radix_passes", C.c_uint32), ("n_sort_records", C.c_uint64)]
 
 
 def _arr(ptr, n, dtype):

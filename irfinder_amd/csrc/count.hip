@@ -81,7 +81,9 @@ constexpr uint32_t kEmpty = 0xffffffffu;
 constexpr uint32_t kLines = K_LINES;     // LDS cache of 16-position lines of the difference planes outside the window
 constexpr uint32_t kWin = K_WIN;         // positions of the LDS difference-array window (both strands in one int32)
 constexpr uint32_t kPCache = 128;         // LDS cache of SpansPoint counters (direct-mapped on the point index)
-constexpr uint32_t kNovelQ = K_NOVELQ;   // LDS queue of novel-junction events per chunk
+constexpr uint32_t kNovelQ = K_NOVELQ;   // LDS queue of novel-junction events per chunk (those the table below has no room for)
+constexpr uint32_t kNovelH = 128;        // LDS table that merges a chunk's novel-junction events by key (open addressing, 4 probes)
+constexpr unsigned long long kEmpty64 = ~0ull;     // (no event has bit 63 set)
 constexpr uint32_t kWinMaxBlocks = 16000;   // more blocks than this in one chunk: a packed 16-bit counter could overflow
 constexpr uint32_t kFragValid = 1u << 31, kFragDir = 1u << 30, kFragBaseMask = (1u << 30) - 1u;   // base is a multiple of 64
 
@@ -97,9 +99,11 @@ struct Lds {
     uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_pos32
     uint32_t pcnt[2][kPCache];
     unsigned long long nq[kNovelQ];
+    unsigned long long nh_key[kNovelH];
+    uint32_t nh_cnt[kNovelH];
     uint32_t chr[kChrBins];
     unsigned long long win, nq_base;
-    uint32_t nq_n, wmax;
+    uint32_t nq_n, nh_n, wmax;
 };
 
 // Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
@@ -179,7 +183,8 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
     for (int k = tid; k < (int)kLines * 16; k += kThreads) S.lcnt[k >> 4][k & 15] = 0;
     for (int k = tid; k < (int)kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
     for (int k = tid; k < (int)kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
-    if (tid == 0) { S.nq_n = 0; S.wmax = 0; }
+    for (int k = tid; k < (int)kNovelH; k += kThreads) { S.nh_key[k] = kEmpty64; S.nh_cnt[k] = 0; }
+    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.wmax = 0; }
     __syncthreads();
 
     const uint32_t lane = tid & 63u;
@@ -504,20 +509,37 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                     }
                 }
                 if (jc[j] && hit[j] == kEmpty) {
-                    // novel junction: a packed event for the sort-reduce at finalize
+                    // novel junction: a packed event for the sort-reduce at finalize.  A chunk sits on one locus, so its
+                    // novel events repeat a handful of keys: they are merged in an LDS table and leave as (key, weight)
                     const uint64_t ev = (gbe[j] << kJuncLeftShift) | ((jkey[j] & ((1ull << kJuncSpanBits) - 1ull)) << 1) | dir;
-                    const uint32_t q = atomicAdd(&S.nq_n, 1u);
-                    if (q < kNovelQ) {
-                        S.nq[q] = ev;
-                    } else {
-                        // queue full (a run without ref-sj.ref): the lanes that got here reserve slots together
-                        const uint64_t m = __ballot(1);
-                        const int lead = __ffsll((long long)m) - 1;
-                        unsigned long long b = 0;
-                        if ((int)lane == lead) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
-                        b = __shfl(b, lead);
-                        const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                        if (slot < T.junc_capacity) T.junc_keys[slot] = ev; else err |= ERR_JUNC_CAPACITY;
+                    const uint32_t h = (uint32_t)((ev * 0x9E3779B97F4A7C15ull) >> 57);
+                    bool merged = false;
+#pragma unroll
+                    for (uint32_t pr = 0; pr < 4u; pr++) {
+                        if (merged) continue;
+                        const uint32_t sl = (h + pr) & (kNovelH - 1u);
+                        unsigned long long cur = S.nh_key[sl];
+                        if (cur == kEmpty64) {
+                            const unsigned long long old = atomicCAS(&S.nh_key[sl], kEmpty64, (unsigned long long)ev);
+                            cur = old == kEmpty64 ? (unsigned long long)ev : old;
+                            if (old == kEmpty64) atomicAdd(&S.nh_n, 1u);
+                        }
+                        if (cur == ev) { atomicAdd(&S.nh_cnt[sl], 1u); merged = true; }
+                    }
+                    if (!merged) {
+                        const uint32_t q = atomicAdd(&S.nq_n, 1u);
+                        if (q < kNovelQ) {
+                            S.nq[q] = ev;
+                        } else {
+                            // table and queue full (a run without ref-sj.ref over a dense locus): the lanes that got here reserve slots together
+                            const uint64_t m = __ballot(1);
+                            const int lead = __ffsll((long long)m) - 1;
+                            unsigned long long b = 0;
+                            if ((int)lane == lead) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
+                            b = __shfl(b, lead);
+                            const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                            if (slot < T.junc_capacity) { T.junc_keys[slot] = ev; T.junc_w[slot] = 1u; } else err |= ERR_JUNC_CAPACITY;
+                        }
                     }
                 }
             }
@@ -529,7 +551,8 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         // ---------------- 3. flush the LDS accumulators ----------------
         // 3a. the junction cache and the SpansPoint cache: counters to the tables
         const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ;
-        if (tid == 0 && nq) S.nq_base = atomicAdd(T.junc_count, (unsigned long long)nq);
+        const uint32_t nh = S.nh_n;
+        if (tid == 0 && nq + nh) S.nq_base = atomicAdd(T.junc_count, (unsigned long long)(nq + nh));
         for (uint32_t e = tid; e < kJCache; e += kThreads) {
             const uint32_t idx = S.jtag[e];
             if (idx != kEmpty) {
@@ -590,11 +613,27 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         __syncthreads();
         CPROF(6);
         for (uint32_t e = tid; e < kLines; e += kThreads) S.ltag[e] = kEmpty;
-        if (tid == 0) { S.nq_n = 0; S.wmax = 0; }
-        if (nq) {
+        if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.wmax = 0; }
+        if (nq + nh) {
+            // records of the chunk: the merged table first (wave 0 compacts it with ballots), then the queue (weight 1)
             const unsigned long long qb = S.nq_base;
+            if (nh && tid < 64u) {
+                uint32_t at = 0;
+#pragma unroll
+                for (uint32_t e0 = 0; e0 < kNovelH; e0 += 64u) {
+                    const unsigned long long k = S.nh_key[e0 + tid];
+                    const uint32_t w = S.nh_cnt[e0 + tid];
+                    const uint64_t occ = __ballot(k != kEmpty64);
+                    if (k != kEmpty64) {
+                        const unsigned long long slot = qb + at + (unsigned long long)__popcll(occ & ((1ull << tid) - 1ull));
+                        if (slot < T.junc_capacity) { T.junc_keys[slot] = k; T.junc_w[slot] = w; } else err |= ERR_JUNC_CAPACITY;
+                        S.nh_key[e0 + tid] = kEmpty64; S.nh_cnt[e0 + tid] = 0;
+                    }
+                    at += (uint32_t)__popcll(occ);
+                }
+            }
             for (uint32_t e = tid; e < nq; e += kThreads) {
-                if (qb + e < T.junc_capacity) T.junc_keys[qb + e] = S.nq[e]; else err |= ERR_JUNC_CAPACITY;
+                if (qb + nh + e < T.junc_capacity) { T.junc_keys[qb + nh + e] = S.nq[e]; T.junc_w[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
             }
         }
     }

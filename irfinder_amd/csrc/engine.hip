@@ -105,7 +105,9 @@ struct irf_ctx {
     DevBuf<uint32_t> d_sp_row, d_sp_cnt;
     DevBuf<uint4> d_bkt;                         // kernels.h: CountTables::bkt
     DevBuf<uint32_t> d_sp_pos32;                 // SpansPoint: low 32 bits of the points' full coordinates, sorted
-    DevBuf<uint64_t> d_junc_a, d_junc_b;
+    DevBuf<uint64_t> d_junc_a, d_junc_b;          // novel-junction records: packed keys (+ sort buffer)
+    DevBuf<uint32_t> d_juncw_a, d_juncw_b;        // ... their weights; d_juncw_a.cap follows d_junc_a.cap
+    DevBuf<uint32_t> d_wex;                       // exclusive scan of the sorted weights
     DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
     DevBuf<uint32_t> d_err;
     DevBuf<uint32_t> d_ws;                       // workspace of the carry scan
@@ -597,6 +599,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     {
         uint64_t cap = std::max<uint64_t>(P.junc_event_capacity, 1024);
         hipError_t e = d_junc_a.reserve(cap);
+        if (e == hipSuccess) e = d_juncw_a.reserve(d_junc_a.cap);
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the junction event buffer failed");
     }
     have_map = true;
@@ -642,7 +645,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
     T.sp_pos32 = d_sp_pos32.p; T.n_sp_dev = (uint32_t)n_sp_dev; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
     T.known_keys = d_known_keys.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
-    T.junc_keys = d_junc_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
+    T.junc_keys = d_junc_a.p; T.junc_w = d_juncw_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
     return T;
 }
 
@@ -657,10 +660,17 @@ int irf_ctx::ensure_junc_capacity(uint64_t n_blk) {
     if (cur + n_blk > d_junc_a.cap) {
         uint64_t ncap = std::max<uint64_t>(d_junc_a.cap * 2, cur + n_blk);
         uint64_t* np = nullptr;
+        uint32_t* nw = nullptr;
         HIP_TRY(hipMalloc((void**)&np, ncap * sizeof(uint64_t)));
-        if (cur) HIP_TRY(hipMemcpy(np, d_junc_a.p, cur * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-        d_junc_a.release();
+        if (hipMalloc((void**)&nw, ncap * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(np); return fail(IRF_E_NOMEM, "hipMalloc of the junction event buffer failed"); }
+        if (cur) {
+            hipError_t e1 = hipMemcpy(np, d_junc_a.p, cur * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+            hipError_t e2 = hipMemcpy(nw, d_juncw_a.p, cur * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+            if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(np); (void)hipFree(nw); return fail(IRF_E_DEVICE, "hipMemcpy of the junction event buffer failed"); }
+        }
+        d_junc_a.release(); d_juncw_a.release();
         d_junc_a.p = np; d_junc_a.cap = ncap;
+        d_juncw_a.p = nw; d_juncw_a.cap = ncap;
     }
     junc_upper = cur + n_blk;
     return 0;
@@ -811,11 +821,14 @@ int irf_ctx::finalize() {
     }
     n_events = scal[0];
     votes[0] = scal[3]; votes[1] = scal[4];
-    if (n_events > 0xffffffffull) return fail(IRF_E_RANGE, "more than 2^32-1 junction events");
+    if (n_events > 0xffffffffull) return fail(IRF_E_RANGE, "more than 2^32-1 junction records");
     n_unique = 0;
     d_sorted = d_junc_a.p;
+    uint32_t n_radix_passes = 0;
     if (n_events) {
-        if (d_junc_b.reserve(d_junc_a.cap) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort buffer failed");
+        // (sized to the records there are, not to the buffer's capacity: a few hundred thousand after the per-chunk merge)
+        if (d_junc_b.reserve(n_events) != hipSuccess || d_juncw_b.reserve(n_events) != hipSuccess || d_wex.reserve(n_events) != hipSuccess)
+            return fail(IRF_E_NOMEM, "hipMalloc of the sort buffer failed");
         uint64_t ws_need = std::max(dev::radix_workspace_elems(n_events), dev::scan_workspace_elems(n_events));
         // the sort has its own workspace: d_ws still holds nothing the statistics need, but keep the two apart
         if (ws_need > d_ws_sort.cap) { if (d_ws_sort.reserve(ws_need) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the sort workspace failed"); }
@@ -828,16 +841,21 @@ int irf_ctx::finalize() {
         const unsigned long long varying = bits[0] ^ bits[1];
         uint64_t* src = d_junc_a.p;
         uint64_t* dst = d_junc_b.p;
+        uint32_t* wsrc = d_juncw_a.p;
+        uint32_t* wdst = d_juncw_b.p;
         for (int shift = 0; shift < 64; shift += 8) {
             if (((varying >> shift) & 0xffull) == 0) continue;     // digit identical in every key
-            dev::launch_radix_pass(src, dst, n_events, shift, d_ws_sort.p, stream);
+            n_radix_passes++;
+            dev::launch_radix_pass(src, dst, wsrc, wdst, n_events, shift, d_ws_sort.p, stream);
             std::swap(src, dst);
+            std::swap(wsrc, wdst);
         }
         d_sorted = src;
         if (d_flags.reserve(n_events) != hipSuccess || d_uidx.reserve(n_events) != hipSuccess)
             return fail(IRF_E_NOMEM, "hipMalloc of the junction compaction buffers failed");
         dev::launch_head_flags(src, n_events, d_flags.p, stream);
         dev::launch_exclusive_scan_u32(d_flags.p, d_uidx.p, n_events, d_ws_sort.p, stream);
+        dev::launch_exclusive_scan_u32(wsrc, d_wex.p, n_events, d_ws_sort.p, stream);
         uint32_t last[2];
         HIP_TRY(hipMemcpyAsync(&last[0], d_uidx.p + (n_events - 1), 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&last[1], d_flags.p + (n_events - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -846,7 +864,7 @@ int irf_ctx::finalize() {
         if (d_ukeys.reserve(n_unique) != hipSuccess || d_ustart.reserve(n_unique) != hipSuccess || d_ucount.reserve(n_unique) != hipSuccess)
             return fail(IRF_E_NOMEM, "hipMalloc of the junction table failed");
         dev::launch_unique_runs(src, d_flags.p, d_uidx.p, n_events, d_ukeys.p, d_ustart.p, stream);
-        dev::launch_run_lengths(d_ustart.p, n_unique, n_events, d_ucount.p, stream);
+        dev::launch_run_sums(d_ustart.p, n_unique, n_events, d_wex.p, wsrc, d_ucount.p, stream);
         // ---- SpliceLeft / SpliceRight contributions of the novel junctions ----
         J.ukeys = d_ukeys.p; J.ucount = d_ucount.p; J.n_unique = n_unique;
         dev::launch_junction_lookups(J, stream);
@@ -869,6 +887,8 @@ int irf_ctx::finalize() {
         if (hipEventElapsedTime(&ms, count_events[i].first, count_events[i].second) == hipSuccess) timing.count_ms += ms;
     }
     timing.n_count_launches = (uint32_t)count_events_used;
+    timing.n_radix_passes = n_radix_passes;
+    timing.n_sort_records = n_events;
     if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) timing.scan_ms = ms;
     if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) timing.junction_ms = ms;
     if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.stats_ms = ms;

@@ -82,7 +82,8 @@ struct CountTables {
     uint32_t n_known;             // entries of known_keys
     uint32_t n_kj;                // rows of the known-junction table
     uint32_t* known_cnt;          // [2][n_kj]
-    uint64_t* junc_keys;          // novel-junction event buffer
+    uint64_t* junc_keys;          // novel-junction event buffer: packed keys ...
+    uint32_t* junc_w;             // ... and their weights (a chunk's events on one junction are merged in LDS first)
     unsigned long long* junc_count;
     uint32_t* err_flags;
 };
@@ -120,14 +121,17 @@ constexpr uint32_t kRadixTile = 4096;
 uint64_t radix_workspace_elems(uint64_t n);     // uint32 elements
 // OR / AND over all keys (to skip constant digits); out[0] = OR, out[1] = AND (pre-set to 0 / ~0)
 void launch_key_bits(const uint64_t* keys, uint64_t n, unsigned long long* out, hipStream_t s);
-// one stable counting pass on digit [shift, shift+8)
-void launch_radix_pass(const uint64_t* in, uint64_t* out, uint64_t n, int shift, uint32_t* workspace, hipStream_t s);
+// one stable counting pass on digit [shift, shift+8); the weights travel with their keys
+void launch_radix_pass(const uint64_t* in, uint64_t* out, const uint32_t* win, uint32_t* wout, uint64_t n, int shift,
+                       uint32_t* workspace, hipStream_t s);
 // sorted keys -> head flags (1 where key differs from predecessor)
 void launch_head_flags(const uint64_t* keys, uint64_t n, uint32_t* flags, hipStream_t s);
 // compaction: unique keys + run lengths.  uidx = exclusive scan of flags.
 void launch_unique_runs(const uint64_t* keys, const uint32_t* flags, const uint32_t* uidx, uint64_t n,
                         uint64_t* ukeys, uint32_t* ustart, hipStream_t s);
-void launch_run_lengths(const uint32_t* ustart, uint64_t n_unique, uint64_t n, uint32_t* ucount, hipStream_t s);
+// count of a unique key = sum of the weights of its run; wex = exclusive scan of the sorted weights w
+void launch_run_sums(const uint32_t* ustart, uint64_t n_unique, uint64_t n, const uint32_t* wex, const uint32_t* w, uint32_t* ucount,
+                     hipStream_t s);
 
 // ---- junction-derived lookups ------------------------------------------------
 struct JuncLookupTables {

@@ -2,9 +2,10 @@
 //
 // Replaces the three std::map<…> updates per junction of ⟨upstream⟩
 // ReadBlockProcessor.cpp JunctionCount::ProcessBlocks (RB-tree insert per
-// event) with: append packed 64-bit (chr+left, span, strand) events during
+// event) with: append packed 64-bit (chr+left, span, strand) events — weighted:
+// the count kernel merges a chunk's events on one junction in LDS first — during
 // counting, then one stable LSD radix sort (8-bit digits, constant digits
-// skipped) + run-length reduction at finalize — for NOVEL junctions; reads on a
+// skipped) + reduction (sum of the weights of every run) at finalize — for NOVEL junctions; reads on a
 // junction listed in ref-sj.ref (the vast majority) are counted in place by the
 // count kernel and never enter the sort.  juncLeft / juncRight are not
 // materialised as maps: their only consumers are the lookups at intron Start /
@@ -26,6 +27,7 @@ constexpr int kWaveChunk = kRadixTile / kWaves;            // 1024 keys per wave
 
 __global__ __launch_bounds__(kThreads) void key_bits_kernel(const uint64_t* __restrict__ keys, uint64_t n,
                                                             unsigned long long* out) {
+    __shared__ unsigned long long s_o[kWaves], s_a[kWaves];
     unsigned long long o = 0ull, a = ~0ull;
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
         const unsigned long long k = keys[i];
@@ -33,7 +35,12 @@ __global__ __launch_bounds__(kThreads) void key_bits_kernel(const uint64_t* __re
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { o |= __shfl_xor(o, d); a &= __shfl_xor(a, d); }
-    if ((threadIdx.x & 63) == 0) { atomicOr(&out[0], o); atomicAnd(&out[1], a); }
+    if ((threadIdx.x & 63) == 0) { s_o[threadIdx.x >> 6] = o; s_a[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {          // one pair of atomics per workgroup (they all hit the same two words)
+        for (int w = 1; w < kWaves; w++) { o |= s_o[w]; a &= s_a[w]; }
+        atomicOr(&out[0], o); atomicAnd(&out[1], a);
+    }
 }
 
 // cnt[digit * n_tiles + tile] = number of keys of the tile with that digit
@@ -54,6 +61,7 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t* __
 
 // Stable scatter.  Order inside a tile is (wave, iteration, lane) = ascending index.
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                 const uint32_t* __restrict__ win, uint32_t* __restrict__ wout,
                                                                  uint64_t n, int shift, uint32_t n_tiles,
                                                                  const uint32_t* __restrict__ off) {
     __shared__ uint32_t s_cnt[kWaves][256];
@@ -63,12 +71,13 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
     const uint64_t lane_lt = (1ull << lane) - 1ull;
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)wave * kWaveChunk + lane;
     uint64_t key[kKeysPerThread];
-    uint32_t rank[kKeysPerThread];
+    uint32_t rank[kKeysPerThread], wgt[kKeysPerThread];
 #pragma unroll
     for (int it = 0; it < kKeysPerThread; it++) {
         const uint64_t i = base + (uint64_t)it * 64u;
         const bool valid = i < n;
         key[it] = valid ? in[i] : 0ull;
+        wgt[it] = valid ? win[i] : 0u;
         const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -99,7 +108,9 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
         const uint64_t i = base + (uint64_t)it * 64u;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
-            out[s_cnt[wave][d] + rank[it]] = key[it];
+            const uint32_t o = s_cnt[wave][d] + rank[it];
+            out[o] = key[it];
+            wout[o] = wgt[it];
         }
     }
 }
@@ -121,10 +132,13 @@ __global__ __launch_bounds__(kThreads) void unique_runs_kernel(const uint64_t* _
     }
 }
 
-__global__ __launch_bounds__(kThreads) void run_lengths_kernel(const uint32_t* __restrict__ ustart, uint64_t nu, uint64_t n,
-                                                               uint32_t* __restrict__ ucount) {
+__global__ __launch_bounds__(kThreads) void run_sums_kernel(const uint32_t* __restrict__ ustart, uint64_t nu, uint64_t n,
+                                                            const uint32_t* __restrict__ wex, const uint32_t* __restrict__ w,
+                                                            uint32_t* __restrict__ ucount) {
     const uint64_t u = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (u < nu) ucount[u] = (u + 1 < nu ? ustart[u + 1] : (uint32_t)n) - ustart[u];
+    if (u >= nu) return;
+    const uint32_t end = u + 1 < nu ? wex[ustart[u + 1]] : wex[n - 1] + w[n - 1];
+    ucount[u] = end - wex[ustart[u]];
 }
 
 __device__ __forceinline__ int64_t find_u64(const uint64_t* __restrict__ a, uint32_t n, uint64_t key) {
@@ -197,18 +211,19 @@ uint64_t radix_workspace_elems(uint64_t n) {
 void launch_key_bits(const uint64_t* keys, uint64_t n, unsigned long long* out, hipStream_t s) {
     if (n == 0) return;
     uint32_t blocks = blocks_for(n);
-    if (blocks > 2048u) blocks = 2048u;
+    if (blocks > 1024u) blocks = 1024u;
     hipLaunchKernelGGL(key_bits_kernel, dim3(blocks), dim3(kThreads), 0, s, keys, n, out);
 }
 
-void launch_radix_pass(const uint64_t* in, uint64_t* out, uint64_t n, int shift, uint32_t* ws, hipStream_t s) {
+void launch_radix_pass(const uint64_t* in, uint64_t* out, const uint32_t* win, uint32_t* wout, uint64_t n, int shift, uint32_t* ws,
+                       hipStream_t s) {
     if (n == 0) return;
     const uint32_t n_tiles = (uint32_t)((n + kRadixTile - 1) / kRadixTile);
     uint32_t* cnt = ws;
     uint32_t* scan_ws = ws + (uint64_t)256 * n_tiles;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(n_tiles), dim3(kThreads), 0, s, in, n, shift, n_tiles, cnt);
     launch_exclusive_scan_u32(cnt, cnt, (uint64_t)256 * n_tiles, scan_ws, s);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(n_tiles), dim3(kThreads), 0, s, in, out, n, shift, n_tiles, (const uint32_t*)cnt);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(n_tiles), dim3(kThreads), 0, s, in, out, win, wout, n, shift, n_tiles, (const uint32_t*)cnt);
 }
 
 void launch_head_flags(const uint64_t* keys, uint64_t n, uint32_t* flags, hipStream_t s) {
@@ -222,9 +237,10 @@ void launch_unique_runs(const uint64_t* keys, const uint32_t* flags, const uint3
     hipLaunchKernelGGL(unique_runs_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, s, keys, flags, uidx, n, ukeys, ustart);
 }
 
-void launch_run_lengths(const uint32_t* ustart, uint64_t nu, uint64_t n, uint32_t* ucount, hipStream_t s) {
+void launch_run_sums(const uint32_t* ustart, uint64_t nu, uint64_t n, const uint32_t* wex, const uint32_t* w, uint32_t* ucount,
+                     hipStream_t s) {
     if (nu == 0) return;
-    hipLaunchKernelGGL(run_lengths_kernel, dim3(blocks_for(nu)), dim3(kThreads), 0, s, ustart, nu, n, ucount);
+    hipLaunchKernelGGL(run_sums_kernel, dim3(blocks_for(nu)), dim3(kThreads), 0, s, ustart, nu, n, wex, w, ucount);
 }
 
 void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s) {

@@ -45,8 +45,16 @@ class Annotation:
     measured_bases: int = 0
     extra: dict = field(default_factory=dict)
 
-    def ref_texts(self):
-        return (self.cover_bed, self.sj_ref, self.read_continues_ref, self.roi_bed)
+    def ref_texts(self, hide_sj_frac=0.0, hide_seed=0):
+        """The four reference files.  hide_sj_frac > 0: that fraction of the ref-sj.ref rows (seeded choice) is withheld
+        from the engine, so the reads simulated over those junctions are NOVEL junctions for it — real RNA-seq always has
+        some (the radix sort-reduce path); the simulator still draws from every transcript."""
+        sj = self.sj_ref
+        if hide_sj_frac > 0.0:
+            lines = sj.splitlines(True)
+            keep = np.random.default_rng(hide_seed).random(len(lines)) >= hide_sj_frac
+            sj = "".join(l for l, k in zip(lines, keep) if k)
+        return (self.cover_bed, sj, self.read_continues_ref, self.roi_bed)
 
 
 def _subtract(s, e, cuts):
