@@ -71,7 +71,21 @@ __device__ uint32_t g_cprof[1024][8];
 #define K_MIN_WGS 3
 #endif
 constexpr int kThreads = K_THREADS;
-constexpr int kVec = 4;                               // consecutive fragments / blocks per lane
+#ifndef K_VEC
+#define K_VEC 4
+#endif
+constexpr int kVec = K_VEC;                           // consecutive fragments / blocks per lane (4: 16-byte loads, 2: 8-byte loads)
+static_assert(kVec == 4 || kVec == 2, "K_VEC");
+// a lane's kVec consecutive elements of a uint32 / uint8 column in one load
+template <int V> struct VecT;
+template <> struct VecT<4> { typedef uint4 u32v; typedef uint32_t u8v; };
+template <> struct VecT<2> { typedef uint2 u32v; typedef uint16_t u8v; };
+typedef VecT<kVec>::u32v U32V;
+typedef VecT<kVec>::u8v U8V;
+struct __attribute__((aligned(4))) Quad { uint32_t v[4]; };      // four consecutive table entries at any dword
+__device__ __forceinline__ void unpack(const uint4& v, uint32_t* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void unpack(const uint2& v, uint32_t* o) { o[0] = v.x; o[1] = v.y; }
+constexpr int kVecLog2 = kVec == 4 ? 2 : 1;
 constexpr int kChunk = kThreads * kVec;               // fragments per workgroup iteration
 constexpr int kChunkLog2 = kChunk == 1024 ? 10 : kChunk == 2048 ? 11 : kChunk == 512 ? 9 : 0;
 static_assert(kChunkLog2 > 0, "K_THREADS");
@@ -194,38 +208,41 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
-    const uint4* __restrict__ chr4 = reinterpret_cast<const uint4*>(B.frag_chr);
-    const uint4* __restrict__ fs4 = reinterpret_cast<const uint4*>(B.frag_start);
-    const uint4* __restrict__ fe4 = reinterpret_cast<const uint4*>(B.frag_end);
-    const uint4* __restrict__ off4 = reinterpret_cast<const uint4*>(B.frag_blk_off);
-    const uint32_t* __restrict__ flg4 = reinterpret_cast<const uint32_t*>(B.frag_flags);
-    const uint4* __restrict__ bs4 = reinterpret_cast<const uint4*>(B.blk_start);
-    const uint4* __restrict__ bl4 = reinterpret_cast<const uint4*>(B.blk_len);
-    const uint32_t* __restrict__ rd4 = reinterpret_cast<const uint32_t*>(B.blk_read);
+    const U32V* __restrict__ chr4 = reinterpret_cast<const U32V*>(B.frag_chr);
+    const U32V* __restrict__ fs4 = reinterpret_cast<const U32V*>(B.frag_start);
+    const U32V* __restrict__ fe4 = reinterpret_cast<const U32V*>(B.frag_end);
+    const U32V* __restrict__ off4 = reinterpret_cast<const U32V*>(B.frag_blk_off);
+    const U8V* __restrict__ flg4 = reinterpret_cast<const U8V*>(B.frag_flags);
+    const U32V* __restrict__ bs4 = reinterpret_cast<const U32V*>(B.blk_start);
+    const U32V* __restrict__ bl4 = reinterpret_cast<const U32V*>(B.blk_len);
+    const U8V* __restrict__ rd4 = reinterpret_cast<const U8V*>(B.blk_read);
     // XCD-aware chunk order: workgroup b runs on XCD b % 8 (round-robin dispatch); every XCD gets a contiguous
     // eighth of the (coordinate-sorted) batch, so that neighbouring chunks — same table lines, overlapping
     // difference windows — share one L2
     const uint32_t xcd = blockIdx.x & 7u, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const uint32_t per_xcd = (n_chunks + 7u) / 8u;
     const uint32_t c_end = (xcd + 1u) * per_xcd < n_chunks ? (xcd + 1u) * per_xcd : n_chunks;
+#ifdef K_INTERLEAVE
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+#else
     for (uint32_t c = xcd * per_xcd + wg_in_xcd; c < c_end; c += wgs_per_xcd) {
+#endif
         const uint32_t f0 = c * kChunk;
         // ---------------- 1. fragment-parallel: fragments f0 + 4 tid .. + 3 ----------------
         {
             // a 16-byte group that starts inside an array never leaves the array's last page: lanes past the end read
             // the last group again and discard it
-            const uint32_t g_last = (B.n_frag - 1u) >> 2;
-            const uint32_t g = (f0 >> 2) + tid < g_last ? (f0 >> 2) + tid : g_last;
-            const uint4 vchr = chr4[g], vfs = fs4[g], vfe = fe4[g], voff = off4[g];
+            const uint32_t g_last = (B.n_frag - 1u) >> kVecLog2;
+            const uint32_t g = (f0 >> kVecLog2) + tid < g_last ? (f0 >> kVecLog2) + tid : g_last;
+            const U32V vchr = chr4[g], vfs = fs4[g], vfe = fe4[g], voff = off4[g];
             const uint32_t vflg = flg4[g];
             if (tid == 0) {
                 const uint32_t last = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
                 const uint32_t o = B.frag_blk_off[last];
                 S.off[kChunk] = o < B.n_blk ? o : B.n_blk;
             }
-            const uint32_t chr[kVec] = {vchr.x, vchr.y, vchr.z, vchr.w};
-            const uint32_t fs[kVec] = {vfs.x, vfs.y, vfs.z, vfs.w}, fe[kVec] = {vfe.x, vfe.y, vfe.z, vfe.w};
-            const uint32_t off[kVec] = {voff.x, voff.y, voff.z, voff.w};
+            uint32_t chr[kVec], fs[kVec], fe[kVec], off[kVec];
+            unpack(vchr, chr); unpack(vfs, fs); unpack(vfe, fe); unpack(voff, off);
             uint32_t key[kVec], clen[kVec];
             uint64_t base[kVec];
             bool in[kVec];
@@ -314,28 +331,30 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
         const unsigned long long win = S.win;
         const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
         uint32_t wmax = 0;
-        const uint32_t g_lastb = B.n_blk ? (B.n_blk - 1u) >> 2 : 0u;
+        const uint32_t g_lastb = B.n_blk ? (B.n_blk - 1u) >> kVecLog2 : 0u;
         // The block columns of an iteration are loaded one iteration ahead (the loads of the first iteration are issued
         // here, before anything waits): a round trip less on the chain columns -> bucket entries -> key / point tables.
         // Every lane also loads the block after its four itself (the junction to the right of its last block).
-        struct BlkCols { uint4 vbs, vbl; uint32_t vrd, nbs, nbl, nrd; };
+        struct BlkCols { U32V vbs, vbl; uint32_t vrd, nbs, nbl, nrd; };
         auto load_cols = [&](uint32_t k0) -> BlkCols {
             BlkCols c;
-            const uint32_t g = (k0 >> 2) < g_lastb ? (k0 >> 2) : g_lastb;
+            const uint32_t g = (k0 >> kVecLog2) < g_lastb ? (k0 >> kVecLog2) : g_lastb;
             const uint32_t kn = k0 + kVec < B.n_blk ? k0 + kVec : (B.n_blk ? B.n_blk - 1u : 0u);
             c.vbs = bs4[g]; c.vbl = bl4[g]; c.vrd = rd4[g];
             c.nbs = B.blk_start[kn]; c.nbl = B.blk_len[kn]; c.nrd = B.blk_read[kn];
             return c;
         };
-        BlkCols nxt = load_cols((kb0 & ~3u) + tid * kVec);
-        for (uint32_t ka = kb0 & ~3u; ka < kb1 && !(T.ablate & 32u); ka += kThreads * kVec) {
+        BlkCols nxt = load_cols((kb0 & ~(uint32_t)(kVec - 1)) + tid * kVec);
+        for (uint32_t ka = kb0 & ~(uint32_t)(kVec - 1); ka < kb1 && !(T.ablate & 32u); ka += kThreads * kVec) {
             const uint32_t k0 = ka + tid * kVec;
             const BlkCols cur = nxt;
             nxt = load_cols(k0 + kThreads * kVec);
             uint32_t bs[kVec + 1], bl[kVec + 1], rd[kVec + 1];
-            bs[0] = cur.vbs.x; bs[1] = cur.vbs.y; bs[2] = cur.vbs.z; bs[3] = cur.vbs.w; bs[4] = cur.nbs;
-            bl[0] = cur.vbl.x; bl[1] = cur.vbl.y; bl[2] = cur.vbl.z; bl[3] = cur.vbl.w; bl[4] = cur.nbl;
-            rd[0] = cur.vrd & 0xffu; rd[1] = (cur.vrd >> 8) & 0xffu; rd[2] = (cur.vrd >> 16) & 0xffu; rd[3] = cur.vrd >> 24; rd[4] = cur.nrd;
+            unpack(cur.vbs, bs); bs[kVec] = cur.nbs;
+            unpack(cur.vbl, bl); bl[kVec] = cur.nbl;
+#pragma unroll
+            for (int j = 0; j < kVec; j++) rd[j] = (cur.vrd >> (8 * j)) & 0xffu;
+            rd[kVec] = cur.nrd;
             // owner = the last fragment of the chunk whose offset is <= k (empty fragments share an offset with
             // their successor and are never picked): binary search for the first block, a short walk for the others
             uint32_t fbv[kVec], clen[kVec];
@@ -401,24 +420,25 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                 if (jc[j] && (bs[j + 1] < be || span >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[j] = false; }
                 jkey[j] = (gbe[j] << kJuncSpanBits) | span;
                 const bool kq = jc[j] && (ee[j].w >> 16);
-                kfirst[j] = T.known_keys[kq ? ee[j].z : 0u];                  // the table holds at least one entry
-                if (!kq) kfirst[j] = ~0ull;
+                kfirst[j] = ~0ull;
+                if (kq) kfirst[j] = T.known_keys[ee[j].z];                    // (only the lanes with a candidate: see the SpansPoint load)
             }
             // SpansPoint: the first four points under every block are requested now, together with the junction keys
             // (one round trip for all four blocks of the lane; points are compared modulo 2^32)
             uint32_t sp_p[kVec], sp_p1[kVec], sp_g[kVec][4];
             {
-                const uint32_t sp_last = T.n_sp_dev ? T.n_sp_dev - 1u : 0u;
 #pragma unroll
                 for (int j = 0; j < kVec; j++) {
                     const bool on = ok[j] && bl[j] > T.sp_min_len && !(T.ablate & 2u);
                     sp_p[j] = es[j].y;
                     sp_p1[j] = on ? ee[j].y + (ee[j].w & 0xffffu) : sp_p[j];      // saturated count: a lower bound, fixed below
+                    // ONE 16-byte load (dword-aligned; the table has four spare entries behind its end) and only by the lanes
+                    // that have candidates: the vector L1 handles about one lane's access per clock whatever its width,
+                    // and this kernel keeps it busy ~90 % of the time (profiles/r02q_count_pmc.txt)
+                    Quad q4 = {{0u, 0u, 0u, 0u}};
+                    if (sp_p[j] < sp_p1[j]) q4 = *reinterpret_cast<const Quad*>(T.sp_pos32 + sp_p[j]);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t i = sp_p[j] + q < sp_last ? sp_p[j] + q : sp_last;
-                        sp_g[j][q] = T.sp_pos32[i];
-                    }
+                    for (int q = 0; q < 4; q++) sp_g[j][q] = q4.v[q];
                 }
             }
             // known junction?  (index into known_keys, or kEmpty)

@@ -398,7 +398,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         }
         n_sp_dev = gpos.size();
         {   // the count kernel compares points with block ends modulo 2^32 (all within one block span of each other)
-            std::vector<uint32_t> lo32(gpos.size());
+            std::vector<uint32_t> lo32(gpos.size() + 4, 0u);     // + four spare entries: the kernel loads four at a time from any index
             for (size_t i = 0; i < gpos.size(); i++) lo32[i] = (uint32_t)gpos[i];
             TRY(upload(this, d_sp_pos32, lo32));
         }
