@@ -78,6 +78,11 @@ typedef struct irf_params {
     /* ---- reader (no upstream counterpart: SURVEY App. D-1) ---- */
     uint32_t mate_join;             /* 0: upstream's pairing, the NEXT record is the mate (name-collated input);
                                        1: coordinate-sorted input, mates are joined by read name            */
+    /* ---- further OQ switches (appended: ABI order of the fields above is unchanged) ---- */
+    uint32_t warn_nonuniform_and;   /* OQ-12 0: NonUniformIntronCover iff max flank > depth*rel + abs (one mixed tolerance);
+                                             1: iff max flank > depth + abs AND max flank > depth*rel (two conditions)   */
+    uint32_t gap_pair_is_intersect; /* OQ-3  an overlapping pair whose read 2 starts in an N gap of read 1 is counted as two
+                                             reads either way; the stdout summary lists it under 0: long pairs, 1: intersect pairs */
 } irf_params;
 
 void irf_params_default(irf_params* p);
@@ -300,7 +305,9 @@ typedef struct irf_reader_stats {
 int irf_reader_create(const irf_params* params, irf_reader** out);
 void irf_reader_destroy(irf_reader* r);
 const char* irf_reader_last_error(const irf_reader* r);
-/* Feed bytes (any chunking).  is_bgzf: 1 = BGZF-compressed, 0 = raw BAM.     */
+/* Feed bytes (any chunking).  is_bgzf: 1 = BGZF-compressed, 0 = raw BAM.  Errors are sticky.  After an error the
+ * batch and the counters hold the records in front of the damaged member / record (the same for any thread count); the
+ * device reader (irf_dreader_feed) refuses the whole feed instead — discard the partial results either way.          */
 int irf_reader_feed(irf_reader* r, const uint8_t* data, size_t len, int is_bgzf);
 /* BGZF members of one irf_reader_feed call are inflated and CRC-checked by n_threads threads (1..64; default 1).
  * No upstream counterpart: ⟨upstream⟩ bin/IRFinder pipes `gzip -cd` (one thread) into the engine.  The record
@@ -343,7 +350,7 @@ typedef struct irf_dreader_timing {     /* sums over all feeds, HIP events on th
     float crc_ms;         /* bgzf_crc_kernel                                                  */
     float chain_ms;       /* record starts: guess, verify rounds, scan (includes host syncs)  */
     float assemble_ms;    /* record index, pairing state, count pass, scans, write pass       */
-    float reserved;
+    uint32_t chain_rounds;/* most verification rounds a feed's record chain needed (2-3 on real data) */
     uint64_t bytes_in;        /* compressed bytes consumed                                    */
     uint64_t bytes_inflated;
     uint64_t n_members;

@@ -47,6 +47,8 @@ class IrfParams(C.Structure):
         ("junc_event_capacity", C.c_uint64),
         ("keep_depth", C.c_uint32),
         ("mate_join", C.c_uint32),
+        ("warn_nonuniform_and", C.c_uint32),
+        ("gap_pair_is_intersect", C.c_uint32),
     ]
 
 
@@ -106,8 +108,8 @@ class IrfReaderStats(C.Structure):
 
 
 class IrfDreaderTiming(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("h2d_ms", "inflate_ms", "crc_ms", "chain_ms", "assemble_ms", "reserved")] + \
-               [(n, C.c_uint64) for n in ("bytes_in", "bytes_inflated", "n_members")]
+    _fields_ = [(n, C.c_float) for n in ("h2d_ms", "inflate_ms", "crc_ms", "chain_ms", "assemble_ms")] + \
+               [("chain_rounds", C.c_uint32)] + [(n, C.c_uint64) for n in ("bytes_in", "bytes_inflated", "n_members")]
 
 
 class IrfLayout(C.Structure):

@@ -312,6 +312,7 @@ __device__ Unit process_unit(const AssembleArgs& A, bool is_pair, const Rec& x, 
     const bool is_long = A.pair_long_inclusive ? (e1 <= pos2) : (e1 < pos2);
     if (!WRITE) st[RS_PAIRS]++;
     u.n_frag = 1;
+    bool gap_pair = false;
     if (!is_long) {
         const bool is_short = A.pair_short_inclusive ? (e1 >= e2) : (e1 > e2);
         if (is_short) {
@@ -336,7 +337,8 @@ __device__ Unit process_unit(const AssembleArgs& A, bool is_pair, const Rec& x, 
             } else st[RS_INTERSECT]++;
             return u;
         }
-        // pos2 in an N gap of read 1 (OQ-3): two separate reads
+        // pos2 in an N gap of read 1 (OQ-3): two separate reads; its class in the summary is a switch
+        gap_pair = true;
     }
     u.n_blk = nb1 + nb2;
     if (WRITE) {
@@ -344,7 +346,7 @@ __device__ Unit process_unit(const AssembleArgs& A, bool is_pair, const Rec& x, 
         for_each_block(a, &t, [&](uint32_t k, uint32_t s, uint32_t l) { put_block(k, s, l, 0); });
         for_each_block(b, &t, [&](uint32_t k, uint32_t s, uint32_t l) { put_block(nb1 + k, s, l, 1); });
         emit_header(chr, dir, pos1, max(e1, e2), true);
-    } else st[RS_LONG]++;
+    } else st[gap_pair && A.gap_pair_is_intersect ? RS_INTERSECT : RS_LONG]++;
     return u;
 }
 

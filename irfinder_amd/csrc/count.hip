@@ -252,6 +252,9 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                 in[j] = i < B.n_frag;
                 const bool ok = in[j] && chr[j] < T.n_chr;
                 if (in[j] && !ok) err |= ERR_CHR_RANGE;
+                // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here):
+                // inside the array's bounds, non-decreasing inside the lane's group (across groups: after the barrier)
+                if (in[j] && (off[j] > B.n_blk || (j > 0 && off[j] < off[j - 1]) || (i == 0u && off[j] != 0u))) err |= ERR_CSR;
                 const uint32_t cc = ok ? chr[j] : 0u;            // the tables hold at least one entry
                 const bool counted = (T.chr_owned[cc] != 0) && ok;
                 base[j] = T.chr_base[cc];
@@ -328,6 +331,9 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
 
         // ---------------- 2. block-parallel: 4 consecutive blocks per lane ----------------
         const uint32_t kb0 = S.off[0], kb1 = S.off[kChunk];
+        // (S.off[kChunk] is the offset behind the chunk's last fragment: the next group's first, or frag_blk_off[n_frag])
+        if (S.off[tid * kVec + kVec - 1] > S.off[tid * kVec + kVec] && f0 + tid * kVec + kVec - 1 < B.n_frag) err |= ERR_CSR;
+        if (tid == 0 && f0 + kChunk >= B.n_frag && B.frag_blk_off[B.n_frag] != B.n_blk) err |= ERR_CSR;
         const unsigned long long win = S.win;
         const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
         uint32_t wmax = 0;

@@ -74,6 +74,7 @@ struct Trace {
 };
 const Trace g_trace;
 
+constexpr uint32_t kVerifyBatch = 8;         // chain_verify launches per host synchronisation (after the first three)
 constexpr uint64_t kMinGap = 1ull << 20;    // bytes kept free in front of a slot's inflated members for the predecessor's carry
 
 inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
@@ -132,6 +133,7 @@ struct irf_dreader {
     hipStream_t stream = nullptr;
     std::string err;
     bool failed = false;
+    int failed_code = IRF_E_PARSE;
 
     // host side
     std::vector<uint8_t> pending;            // compressed bytes not consumed yet (a partial member, or an incomplete header)
@@ -170,7 +172,7 @@ struct irf_dreader {
     DBuf<uint32_t> d_count, d_seg_base, d_rec_nf, d_tile_last, d_tile_carry, d_fr, d_bl, d_ws;
     DBuf<uint64_t> d_guess, d_exit, d_rec_off;
     DBuf<unsigned long long> d_scal;         // [0] record error, [1 .. 1 + RS_COUNT) reader statistics
-    DBuf<uint32_t> d_flags;                  // [0] chain changed, [2] dangling
+    DBuf<uint32_t> d_flags;                  // [0] dangling, [8 .. 8 + kVerifyBatch) chain changed, one word per verify launch of a batch
     OutSlot out[2];
     int out_cur = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};      // stage 2: begin, chain done, assembled
@@ -178,7 +180,7 @@ struct irf_dreader {
     std::mutex err_mutex;                    // stage 1 and stage 2 of neighbouring feeds run on two host threads
     int fail(int code, const std::string& msg) {
         std::lock_guard<std::mutex> g(err_mutex);
-        if (!failed) err = msg;              // the first error stays
+        if (!failed) { err = msg; failed_code = code; }      // the first error stays, text and code: later calls return it
         failed = true;
         return code;
     }
@@ -214,7 +216,7 @@ int irf_dreader::init() {
     memset(&stats, 0, sizeof stats);
     memset(&timing, 0, sizeof timing);
     MEM_TRY(d_scal.reserve(1 + dev::RS_COUNT));
-    MEM_TRY(d_flags.reserve(4));
+    MEM_TRY(d_flags.reserve(8 + kVerifyBatch));
     return 0;
 }
 
@@ -256,7 +258,7 @@ int irf_dreader::host_header(const TwoSpan& in, size_t n_avail) {
 }
 
 int irf_dreader::feed(const uint8_t* data, size_t len) {
-    if (failed) return IRF_E_PARSE;
+    if (failed) return failed_code;
     HIP_TRY(hipSetDevice(device));
     fed = true;
     const TwoSpan in{pending.data(), pending.size(), data, len};
@@ -367,7 +369,7 @@ int irf_dreader::stage1(InSlot& S, const TwoSpan& in, size_t consumed_in, uint64
 // Stage 2: [carry | inflated members] -> fragments of out[out_cur ^ 1], new carry.  Synchronous.
 int irf_dreader::stage2(InSlot& S) {
     const uint32_t n_members = S.n_members;
-    uint32_t* const f_changed = d_flags.p, *const f_dangling = d_flags.p + 2;
+    uint32_t* const f_changed = d_flags.p + 8, *const f_dangling = d_flags.p;
     g_trace.mark("stage2: begin");
     HIP_TRY(hipStreamWaitEvent(stream, S.ev[4], 0));
     uint32_t first_bad = 0;
@@ -420,15 +422,22 @@ int irf_dreader::stage2(InSlot& S) {
         C.guess = d_guess.p; C.exit_ = d_exit.p; C.count = d_count.p; C.changed = f_changed;
         HIP_TRY(hipMemsetAsync(d_count.p + n_seg, 0, 4, stream));
         dev::launch_chain_guess(C, stream);
-        for (uint64_t round = 0;; round++) {
-            uint32_t changed = 0;
-            HIP_TRY(hipMemsetAsync(f_changed, 0, 4, stream));
-            dev::launch_chain_verify(C, stream);
-            HIP_TRY(hipMemcpyAsync(&changed, f_changed, 4, hipMemcpyDeviceToHost, stream));
+        // Verification rounds until one changes nothing.  A round is one launch; the host looks at the flags of a BATCH
+        // of launches at a time (3 first: real data settles in 2-3 rounds = one synchronisation; then kVerifyBatch), so
+        // input whose payload keeps forming plausible but wrong record chains costs launches, not round trips.
+        uint64_t rounds = 0;
+        for (bool settled = false; !settled;) {
+            const uint32_t nb = rounds == 0 ? 3u : kVerifyBatch;
+            uint32_t changed[kVerifyBatch];
+            HIP_TRY(hipMemsetAsync(f_changed, 0, 4 * nb, stream));
+            for (uint32_t k = 0; k < nb; k++) { C.changed = f_changed + k; dev::launch_chain_verify(C, stream); }
+            HIP_TRY(hipMemcpyAsync(changed, f_changed, 4 * nb, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (!changed) break;
-            if (round > (uint64_t)n_seg + 2) return fail(IRF_E_DEVICE, "record chain did not settle (internal error)");
+            for (uint32_t k = 0; k < nb && !settled; k++) { rounds++; settled = changed[k] == 0u; }
+            if (!settled && rounds > (uint64_t)n_seg + 2 + kVerifyBatch) return fail(IRF_E_DEVICE, "record chain did not settle (internal error)");
         }
+        if (rounds > timing.chain_rounds) timing.chain_rounds = (uint32_t)rounds;
+        if (g_trace.on && rounds > 4) fprintf(stderr, "[dreader] record chain needed %llu verification rounds over %u segments\n", (unsigned long long)rounds, n_seg);
         dev::launch_exclusive_scan_u32(d_count.p, d_seg_base.p, (uint64_t)n_seg + 1, d_ws.p, stream);
         HIP_TRY(hipMemcpyAsync(&n_rec, d_seg_base.p + n_seg, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&tail_off, d_exit.p + (n_seg - 1), 8, hipMemcpyDeviceToHost, stream));
@@ -461,7 +470,7 @@ int irf_dreader::stage2(InSlot& S) {
         dev::launch_chain_emit(C, d_seg_base.p, R, stream);
         dev::launch_pair_state(d_rec_nf.p, n_rec, d_tile_last.p, d_tile_carry.p, stream);
         A.buf = raw; A.n_rec = n_rec; A.n_ref = n_ref; A.R = R; A.tile_carry = d_tile_carry.p;
-        A.skip_flag_mask = P.skip_flag_mask; A.pair_long_inclusive = P.pair_long_inclusive; A.pair_short_inclusive = P.pair_short_inclusive;
+        A.skip_flag_mask = P.skip_flag_mask; A.pair_long_inclusive = P.pair_long_inclusive; A.pair_short_inclusive = P.pair_short_inclusive; A.gap_pair_is_intersect = P.gap_pair_is_intersect;
         A.fr_cnt = d_fr.p; A.bl_cnt = d_bl.p; A.stats = d_scal.p + 1; A.dangling = f_dangling;
         HIP_TRY(hipMemsetAsync(d_fr.p + n_rec, 0, 4, stream));
         HIP_TRY(hipMemsetAsync(d_bl.p + n_rec, 0, 4, stream));
@@ -528,7 +537,7 @@ int irf_dreader::stage2(InSlot& S) {
 }
 
 int irf_dreader::finish() {
-    if (failed) return IRF_E_PARSE;
+    if (failed) return failed_code;
     if (inflight >= 0) {
         // pipeline: the last feed's stage 2; its fragments are the batch after this call
         HIP_TRY(hipSetDevice(device));

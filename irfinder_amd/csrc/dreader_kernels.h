@@ -77,7 +77,7 @@ struct AssembleArgs {
     int32_t n_ref;
     RecordIndex R;
     const uint32_t* tile_carry;   // [tiles] (index of the last unpaired record before the tile) + 1, 0: none
-    uint32_t skip_flag_mask, pair_long_inclusive, pair_short_inclusive;
+    uint32_t skip_flag_mask, pair_long_inclusive, pair_short_inclusive, gap_pair_is_intersect;
     uint32_t* fr_cnt;             // [n_rec+1] fragments the record completes (0/1); after the scan: their offset
     uint32_t* bl_cnt;             // [n_rec+1] aligned blocks of that fragment; after the scan: their offset
     unsigned long long* stats;    // [RS_COUNT]

@@ -77,6 +77,7 @@ struct irf_ctx {
     hipStream_t stream = nullptr, copy_stream = nullptr;
     std::string err;
     bool have_map = false, finalized = false, results_ready = false;
+    bool kj_depth_applied = false;               // the known-junction difference events of this sample are in the planes (finalize may be called again after a failure)
 
     // ---- chromosome map ----
     uint32_t n_chr = 0;                          // BAM references
@@ -622,6 +623,7 @@ int irf_ctx::zero_counters() {
     n_fragments = n_blocks = junc_upper = 0;
     n_unique = n_events = 0;
     finalized = results_ready = false;
+    kj_depth_applied = false;
     directionality = 0;
     count_events_used = 0;
     memset(&timing, 0, sizeof timing);
@@ -778,7 +780,7 @@ void irf_ctx::launch_stats(int t, int dirn) {
     T.directionality = dirn;
     T.warn_lowcover_min = P.warn_lowcover_min; T.warn_lowsplice_min = P.warn_lowsplice_min;
     T.warn_minor_ratio = P.warn_minor_ratio; T.warn_nonuniform_rel = P.warn_nonuniform_rel;
-    T.warn_nonuniform_abs = P.warn_nonuniform_abs;
+    T.warn_nonuniform_abs = P.warn_nonuniform_abs; T.warn_nonuniform_and = P.warn_nonuniform_and;
     T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
     dev::launch_intron_stats(T, stats_classes, stream);
 }
@@ -792,7 +794,10 @@ int irf_ctx::finalize() {
     // Everything that needs no answer from the device is queued before the first synchronisation: the depth carries
     // (exclusive scan of the per-segment sums the count kernel kept next to the planes) and the known-junction
     // lookups with the strandedness vote (known junctions were counted in place; novel ones never vote).
-    dev::launch_known_junction_depth(count_tables(), stream);
+    if (!kj_depth_applied) {        // once per sample: a second irf_finalize after a failed one must not add them again
+        dev::launch_known_junction_depth(count_tables(), stream);
+        kj_depth_applied = true;
+    }
     if (env_u64("IRF_RESCAN_PLANES", 0)) dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_seg_sum.p, stream);     // diagnostic: recompute the sums from the planes
     dev::launch_exclusive_scan_u32(d_seg_sum.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[1], stream));
@@ -816,8 +821,8 @@ int irf_ctx::finalize() {
     HIP_TRY(hipStreamSynchronize(stream));
     if (errf) {
         char m[160];
-        snprintf(m, sizeof m, "count kernel reported input errors (flags 0x%x: 1 chr id, 2 block beyond chromosome, 4 junction range, 8 junction capacity)", errf);
-        return fail(errf & dev::ERR_JUNC_CAPACITY ? IRF_E_STATE : IRF_E_RANGE, m);
+        snprintf(m, sizeof m, "count kernel reported input errors (flags 0x%x: 1 chr id, 2 block beyond chromosome, 4 junction range, 8 junction capacity, 32 frag_blk_off of a device batch)", errf);
+        return fail(errf & dev::ERR_JUNC_CAPACITY ? IRF_E_STATE : ((errf & dev::ERR_CSR) ? IRF_E_ARG : IRF_E_RANGE), m);
     }
     n_events = scal[0];
     votes[0] = scal[3]; votes[1] = scal[4];

@@ -35,7 +35,8 @@ enum ErrBits : uint32_t {
     ERR_BLOCK_RANGE = 2u,      // block end beyond the chromosome length
     ERR_JUNC_RANGE = 4u,       // junction span or coordinate does not fit the packed key
     ERR_JUNC_CAPACITY = 8u,    // junction event buffer full (host sizing bug)
-    ERR_STATS_DEPTH = 16u      // depth beyond what the rank-select levels cover
+    ERR_STATS_DEPTH = 16u,     // depth beyond what the rank-select levels cover
+    ERR_CSR = 32u              // frag_blk_off of a device-resident batch: not non-decreasing, beyond n_blk, or not spanning [0, n_blk]
 };
 
 struct CountTables {
@@ -238,7 +239,7 @@ struct IntronTables {
     uint32_t n_kj;
     uint32_t ablate;               // diagnostic only (IRF_ABLATE_STATS): bit0 no depth pass, bit1 no row tail
     // parameters
-    uint32_t trim_centre_pct, pct_interpolate, flank_offset, flank_len, flank_use_measured;
+    uint32_t trim_centre_pct, pct_interpolate, flank_offset, flank_len, flank_use_measured, warn_nonuniform_and;
     int32_t directionality;        // 0: non-directional table (both planes)
     double warn_lowcover_min, warn_lowsplice_min, warn_minor_ratio, warn_nonuniform_rel, warn_nonuniform_abs;
     // outputs

@@ -762,7 +762,8 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
         if ((double)je + depth < T.warn_lowcover_min) warn = 1;
         else if ((double)je < T.warn_lowsplice_min) warn = 2;
         else if ((double)je * T.warn_minor_ratio < (double)smax) warn = 3;
-        else if (maxflank > depth * T.warn_nonuniform_rel + T.warn_nonuniform_abs) warn = 4;
+        else if (T.warn_nonuniform_and ? (maxflank > depth + T.warn_nonuniform_abs && maxflank > depth * T.warn_nonuniform_rel)
+                                       : (maxflank > depth * T.warn_nonuniform_rel + T.warn_nonuniform_abs)) warn = 4;
         else warn = 0;
         const uint64_t n = T.n_intron;
         const uint64_t i = r_row;

@@ -225,7 +225,11 @@ int BamReader::inflate_blocks() {
     if (parse_rc != 0) return parse_rc;
     const size_t fb = first_bad.load();
     if (fb < zblocks_.size()) {
+        // Everything in front of the corrupt member is parsed, whatever the thread count (the four-wave path may or may not
+        // have parsed it already), so batch and counters after the error do not depend on irf_reader_set_threads.  They
+        // are still not what a caller should keep: the input is damaged (include/irf.h: irf_reader_feed).
         raw_.resize(at + zblocks_[fb].out_off);
+        (void)parse_raw(raw_.size(), false);
         error = why[fb] == 2 ? "BGZF: CRC mismatch" : "BGZF: inflate failed";
         return IRF_E_PARSE;
     }
@@ -393,6 +397,7 @@ void BamReader::emit_pair(const Rec& a, const Rec& b) {
     const uint32_t chr = (uint32_t)a.ref_id;
     const bool is_long = P.pair_long_inclusive ? (e1 <= pos2) : (e1 < pos2);
     stats.n_pairs++;
+    bool gap_pair = false;
     if (!is_long) {
         const bool is_short = P.pair_short_inclusive ? (e1 >= e2) : (e1 > e2);
         if (is_short) {                      // read 2 inside read 1: read-1 blocks only
@@ -412,9 +417,10 @@ void BamReader::emit_pair(const Rec& a, const Rec& b) {
                 return;
             }
         }
-        // pos2 falls in an N gap of read 1 (OQ-3): handled as two separate reads
+        // pos2 falls in an N gap of read 1 (OQ-3): handled as two separate reads; its class in the summary is a switch
+        gap_pair = true;
     }
-    stats.n_pairs_long++;
+    if (gap_pair && P.gap_pair_is_intersect) stats.n_pairs_intersect++; else stats.n_pairs_long++;
     batch.add(chr, dir, pos1, std::max(e1, e2), b1_.data(), b1_.size(), b2_.data(), b2_.size(), true);
 }
 

@@ -598,7 +598,8 @@ public:
             if ((double)o.splice_exact + o.depth < P.warn_lowcover_min) o.warning = IRF_WARN_LOWCOVER;
             else if ((double)o.splice_exact < P.warn_lowsplice_min) o.warning = IRF_WARN_LOWSPLICING;
             else if ((double)o.splice_exact * P.warn_minor_ratio < (double)smax) o.warning = IRF_WARN_MINORISOFORM;
-            else if (maxflank > o.depth * P.warn_nonuniform_rel + P.warn_nonuniform_abs) o.warning = IRF_WARN_NONUNIFORM;
+            else if (P.warn_nonuniform_and ? (maxflank > o.depth + P.warn_nonuniform_abs && maxflank > o.depth * P.warn_nonuniform_rel)
+                                           : (maxflank > o.depth * P.warn_nonuniform_rel + P.warn_nonuniform_abs)) o.warning = IRF_WARN_NONUNIFORM;
             else o.warning = IRF_WARN_NONE;
             rows.push_back(o);
         }
@@ -777,7 +778,8 @@ public:
                 st.n_pairs_intersect++;
                 merged = true;
             } else {
-                st.n_pairs_long++;      /* OQ-3: pos2 in an N gap of read 1: two reads, originals */
+                /* OQ-3: pos2 in an N gap of read 1: two reads, originals; the summary class is a switch */
+                if (P.gap_pair_is_intersect) st.n_pairs_intersect++; else st.n_pairs_long++;
             }
         }
         if (!merged) {

@@ -174,9 +174,10 @@ def test_device_reader_edge_records_and_switches():
     assert (dn, dl) == (chrs, lens) and db.n_frag == 0 and ds["n_records"] == 0
     # the reader's switches (OQ-1/2/3)
     recs = [dict(ref_id=0, pos=100, flag=0x63, cigar="50M"), dict(ref_id=0, pos=150, flag=0x93, cigar="50M"),
-            dict(ref_id=0, pos=100, flag=0x63 | 0x100, cigar="50M"), dict(ref_id=0, pos=400, flag=0x93, cigar="50M")]
+            dict(ref_id=0, pos=100, flag=0x63 | 0x100, cigar="50M"), dict(ref_id=0, pos=400, flag=0x93, cigar="50M"),
+            dict(ref_id=0, pos=1000, flag=0x63, cigar="30M500N30M"), dict(ref_id=0, pos=1200, flag=0x93, cigar="400M")]    # read 2 starts in read 1's N gap
     bam = records_to_bam(chrs, lens, recs)
-    for over in ({}, {"pair_long_inclusive": 1}, {"skip_flag_mask": 0x104}, {"pair_short_inclusive": 0}):
+    for over in ({}, {"pair_long_inclusive": 1}, {"skip_flag_mask": 0x104}, {"pair_short_inclusive": 0}, {"gap_pair_is_intersect": 1}):
         ob, ost, _ = orc.bam_to_batch(bam, orc.default_params(**over))
         _, db, ds, _ = device_read(bgzf_compress(bam), **over)
         assert db.equals(ob) and ds == ost, over
@@ -212,8 +213,9 @@ def test_device_reader_record_payload_that_looks_like_records():
     ob, ost, rc = orc.bam_to_batch(bam)
     assert rc == 0 and ob.n_frag == 3000
     for pieces, pipeline in ((None, False), ([5000], False), ([5000], True)):
-        _, db, ds, _ = device_read(bgzf_compress(bam, block=0x4000), pieces, pipeline)
+        _, db, ds, d = device_read(bgzf_compress(bam, block=0x4000), pieces, pipeline)
         assert db.equals(ob) and ds == ost
+        assert 1 <= d.timing()["chain_rounds"] < 200            # reported: rounds beyond 2-3 mean the speculation was fooled
 
 
 def test_device_reader_fault_injection():
@@ -232,8 +234,9 @@ def test_device_reader_fault_injection():
     d = engine.DeviceReader()
     with pytest.raises(engine.IrfError, match="BGZF"):
         d.feed(bytes(bad))
-    with pytest.raises(engine.IrfError):
-        d.feed(z)                                              # the error is sticky
+    with pytest.raises(engine.IrfError) as e2:
+        d.feed(z)                                              # the error is sticky: same code, same text
+    assert e2.value.code == -2 and "BGZF" in str(e2.value)
     d = engine.DeviceReader()
     d.feed(z[:-40])
     with pytest.raises(engine.IrfError, match="truncated block"):

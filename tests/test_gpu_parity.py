@@ -118,13 +118,59 @@ def test_depth_matches_fragmentsmap():
 
 @pytest.mark.parametrize("over", [dict(flank_use_measured=0), dict(sp_inclusive=1), dict(pct_interpolate=0),
                                   dict(trim_centre_pct=100), dict(trim_centre_pct=0), dict(junc_min_flank=1),
-                                  dict(flank_offset=0, flank_len=200), dict(dir_ratio=1)])
+                                  dict(flank_offset=0, flank_len=200), dict(dir_ratio=1), dict(warn_nonuniform_and=1)])
 def test_oq_switches(over):
     ann, sim = small_world(seed=21, stranded=True)
     names, lens, batch = read_batch(sim.bam(0, 12000))
     e, g = run_gpu(ann.ref_texts(), names, lens, split(batch, 2), **over)
     o, c = run_orc(ann.ref_texts(), names, lens, [batch], **over)
     assert_results_equal(g, c, rel=0.0, what=str(over))
+
+
+def test_device_batch_with_malformed_csr_offsets_is_reported():
+    """frag_blk_off of a device-resident batch (a third-party producer) is checked by the count kernel itself: the host
+    cannot read it.  Not non-decreasing / beyond n_blk / not spanning [0, n_blk] -> irf_finalize fails with IRF_E_ARG."""
+    import torch
+    from irfinder_amd._abi import Batch as B_
+    ann, sim = small_world(seed=2)
+    names, lens, batch = read_batch(sim.bam(0, 3000))
+    ref = engine.RefTables.from_texts(ann.ref_texts())
+    e = engine.Engine(ref)
+    e.chr_map_update(names, lens)
+
+    def run_with(off):
+        e.reset()
+        t = {n: torch.from_numpy(np.ascontiguousarray(off if n == "frag_blk_off" else getattr(batch, n))).cuda() for n, _ in B_.FIELDS}
+        e.submit(engine.device_batch(t, batch.n_frag, batch.n_blk))
+        e.sync()
+        e.finalize()
+
+    good = batch.frag_blk_off.copy()
+    run_with(good)                                            # the unmodified offsets pass
+    o, c = run_orc(ann.ref_texts(), names, lens, [batch])
+    assert_results_equal(e.results(), c, rel=0.0, what="device batch")
+    for name, edit in (("decreasing inside a group", lambda a: a.__setitem__(5, a[4] - 1 if a[4] else a[6] + 1)),
+                       ("decreasing across groups", lambda a: a.__setitem__(1024, a[1023] - 1)),
+                       ("beyond n_blk", lambda a: a.__setitem__(2000, batch.n_blk + 7)),
+                       ("does not start at 0", lambda a: a.__setitem__(0, 1)),
+                       ("does not end at n_blk", lambda a: a.__setitem__(batch.n_frag, batch.n_blk - 1))):
+        bad = good.copy()
+        edit(bad)
+        with pytest.raises(engine.IrfError) as ei:
+            run_with(bad)
+        assert ei.value.code == -1, name
+
+
+def test_oq12_kat_row_on_the_gpu():
+    """depth 10, largest flank measure 16: '-' under the single mixed tolerance, NonUniformIntronCover under the
+    two-condition form (tests/test_oracle_kat.py: the same vectors on the oracle)."""
+    from test_oracle_kat import CHR, LEN, OQ12_REFS, oq12_records
+    names, lens, batch = read_batch(records_to_bam(CHR, LEN, oq12_records()))
+    for over, want in (({}, 0), (dict(warn_nonuniform_and=1), 4)):
+        e, g = run_gpu(OQ12_REFS, names, lens, [batch], **over)
+        o, c = run_orc(OQ12_REFS, names, lens, [batch], **over)
+        assert_results_equal(g, c, rel=0.0, what=str(over))
+        assert g["nondir"]["warning"][0] == want and g["nondir"]["intron_depth"][0] == 10.0 and g["nondir"]["first50"][0] == 16.0
 
 
 def test_novel_junctions_and_many_events_per_thread():

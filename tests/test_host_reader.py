@@ -130,9 +130,10 @@ def test_reader_edge_records():
 def test_oq_switches_reach_the_reader():
     chrs, lens = ["c1"], [10000]
     recs = [dict(ref_id=0, pos=100, flag=0x63, cigar="50M"), dict(ref_id=0, pos=150, flag=0x93, cigar="50M"),
-            dict(ref_id=0, pos=100, flag=0x63 | 0x100, cigar="50M"), dict(ref_id=0, pos=400, flag=0x93, cigar="50M")]
+            dict(ref_id=0, pos=100, flag=0x63 | 0x100, cigar="50M"), dict(ref_id=0, pos=400, flag=0x93, cigar="50M"),
+            dict(ref_id=0, pos=1000, flag=0x63, cigar="30M500N30M"), dict(ref_id=0, pos=1200, flag=0x93, cigar="400M")]    # read 2 starts in read 1's N gap
     bam = records_to_bam(chrs, lens, recs)
-    for over in ({}, {"pair_long_inclusive": 1}, {"skip_flag_mask": 0x104}, {"pair_short_inclusive": 0}):
+    for over in ({}, {"pair_long_inclusive": 1}, {"skip_flag_mask": 0x104}, {"pair_short_inclusive": 0}, {"gap_pair_is_intersect": 1}):
         ob, ost, _ = orc.bam_to_batch(bam, orc.default_params(**over))
         r = engine.Reader(engine.default_params(**over))
         r.feed(bam)
@@ -225,13 +226,22 @@ def test_threaded_bgzf_decode_is_identical_and_reports_the_same_errors():
     # a corrupted member in the middle: same sticky error either way, nothing after it is parsed
     bad = bytearray(z)
     bad[len(z) // 2] ^= 0x55
-    msgs = []
-    for threads in (1, 4):
+    msgs, after = [], []
+    for threads, where in ((1, len(z) // 2), (4, len(z) // 2), (1, len(z) * 7 // 8), (4, len(z) * 7 // 8), (2, len(z) * 7 // 8)):
+        bad = bytearray(z)
+        bad[where] ^= 0x55
         r = engine.Reader(threads=threads)
         with pytest.raises(engine.IrfError) as ei:
             r.feed(bytes(bad), bgzf=True)
             r.finish()
         msgs.append(str(ei.value))
+        after.append((where, r.stats(), r.take_batch()))
     assert msgs[0] == msgs[1] and "BGZF" in msgs[0]
+    # what the reader holds after the error (the records in front of the damaged member) does not depend on the thread count
+    for a in after:
+        for b in after:
+            if a[0] == b[0]:
+                assert a[1] == b[1] and a[2].equals(b[2])
+    assert after[2][1]["n_records"] > after[0][1]["n_records"] > 0
     with pytest.raises(engine.IrfError):
         engine.Reader(threads=0)

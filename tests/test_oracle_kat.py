@@ -183,6 +183,43 @@ def test_kat8_irratio_and_warning():
     assert t["warning"][0] == 1          # 5 + 2.9 < 10 -> LowCover
 
 
+OQ12_REFS = ("chrA\t1000\t3000\tG2/ENSG2/+/1/1000/3000/clean\t0\t+\t1000\t3000\t255,0,0\t1\t2000\t0\n", "chrA\t1000\t3000\t+\n",
+             "chrA\t1000\t+\nchrA\t3000\t+\n", "chrA\t50000\t60000\tROI0\n")
+
+
+def oq12_records():
+    """IntronDepth 10, largest flank measure 16 (first-50 median; ExonToIntronReadsLeft 6), SpliceExact 5."""
+    recs = [dict(ref_id=0, pos=1000, flag=0, cigar="2000M", name="d%d" % k) for k in range(10)]      # depth 10 over the intron
+    recs += [dict(ref_id=0, pos=950, flag=0, cigar="110M", name="x%d" % k) for k in range(6)]        # +6 on [1000,1060), span point 1000
+    recs += [dict(ref_id=0, pos=900, flag=0, cigar="100M2000N100M", name="s%d" % k) for k in range(5)]
+    return recs
+
+
+def test_oq12_nonuniform_single_tolerance_vs_two_conditions():
+    """The KAT row that tells the two recalled forms of the NonUniformIntronCover test apart: depth 10, max flank 16.
+    warn_nonuniform_and = 0 (default): 16 > 10*1.5 + 4 = 19 is false -> '-';  = 1: 16 > 10 + 4 and 16 > 10*1.5 -> warning."""
+    o, r = run(oq12_records(), refs=OQ12_REFS)
+    t = r["nondir"]
+    assert t["intron_depth"][0] == 10.0 and t["first50"][0] == 16.0 and t["last50"][0] == 10.0
+    assert (t["sp_left"][0], t["sp_right"][0], t["splice_exact"][0]) == (6, 0, 5)
+    assert t["warning"][0] == 0
+    o, r = run(oq12_records(), refs=OQ12_REFS, warn_nonuniform_and=1)
+    assert r["nondir"]["warning"][0] == 4
+    assert r["nondir"]["intron_depth"][0] == 10.0
+
+
+def test_oq3_gap_pair_summary_class():
+    """An overlapping pair whose read 2 starts in an N gap of read 1: two reads either way; the summary class is a switch."""
+    recs = pair(100, "30M500N30M", 300, "40M")          # e1 = 660 > pos2 = 300 (not Long), e1 > e2 = 340?  no: Short needs e1 >= e2
+    b, st = frags(recs)
+    assert st["n_pairs_short"] == 1                     # (read 2 inside read 1's span: Short, read-1 blocks only)
+    recs = pair(100, "30M500N30M", 300, "400M")         # pos2 in the gap, e2 = 700 > e1 = 660: neither Long nor Short
+    b, st = frags(recs)
+    assert (st["n_pairs_long"], st["n_pairs_intersect"]) == (1, 0) and len(blocks_of(b, 0)) == 3 and int(b.frag_flags[0]) & 2
+    b2, st2 = frags(recs, gap_pair_is_intersect=1)
+    assert (st2["n_pairs_long"], st2["n_pairs_intersect"]) == (0, 1) and b2.equals(b)
+
+
 def test_outputs_written(tmp_path):
     o, r = run(kat4_records() + [dict(ref_id=0, pos=40, flag=0, cigar="50M120N30M")])
     o.write_outputs(str(tmp_path))
