@@ -257,6 +257,37 @@ typedef enum irf_column {
     IRF_COL_KNOWN_CNT = 9        /* [2][n_ref_junction] uint32, ref-sj rows sorted by (slot,left,right) */
 } irf_column;
 int irf_export_device(irf_ctx* ctx, uint32_t what, void* dst_device, uint64_t* n);
+/* IR tables of a context that does not own every BAM reference leave irf_export_device with the rows of introns on
+ * references it does not own set to zero, so that the shards' columns can simply be added (RCCL reduce(SUM), or
+ * irf_import_device).  Introns on no BAM reference at all belong to no shard: OR this flag into `what` on ONE rank
+ * (the root) to keep its rows for them (all-zero depth, LowCover — what a single-GPU run reports).                  */
+#define IRF_COL_KEEP_ORPHANS 0x100u
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU collection for C / C++ hosts (SURVEY.md §8 e; no upstream counterpart: upstream is one process).
+ *
+ * One process per GPU (north_star): every rank finalizes its chromosomes, then
+ *   1. irf_get_votes -> ncclAllReduce(sum) of the two integers -> irf_finalize_directional on every rank;
+ *   2. per fixed-shape column (IRF_COL_IR_*, SP_CNT, ROI_CNT, CHR_CNT, KNOWN_CNT): irf_export_device into a device
+ *      buffer, ncclReduce(sum) to the root (or ncclSend / ncclRecv + irf_import_device on the root), root: irf_import_device
+ *      of the reduced peers' sum — or, simpler, reduce straight into a buffer and import it once;
+ *   3. novel junctions (their packed keys depend on the shard's layout): irf_export_junctions on every rank, the rows
+ *      sent as plain uint32 arrays (ncclSend / ncclRecv of 5 x n words), irf_import_junctions on the root;
+ *   4. irf_get_results / irf_write_outputs on the root give the whole sample's tables and files.
+ * One process driving several contexts (threads, or several contexts on one GPU): irf_gather does all four steps with
+ * peer copies.  INTEGRATION.md §5 shows both.                                                                      */
+
+/* Adds a column exported by another shard (already on this context's device) into this context's table.  `what` is
+ * one of the fixed-shape columns; n must equal this context's element count.                                      */
+int irf_import_device(irf_ctx* ctx, uint32_t what, const void* src_device, uint64_t n);
+/* Novel junctions of this context as coordinates, sorted by (BAM refID, left, right), host arrays.  Call with all
+ * arrays NULL to get the row count in *n; else *n is the capacity on entry and the row count on return.             */
+int irf_export_junctions(irf_ctx* ctx, uint64_t* n, uint32_t* chr, uint32_t* left, uint32_t* right, uint32_t* cnt_neg, uint32_t* cnt_pos);
+int irf_import_junctions(irf_ctx* ctx, uint64_t n, const uint32_t* chr, const uint32_t* left, const uint32_t* right,
+                         const uint32_t* cnt_neg, const uint32_t* cnt_pos);
+/* In-process collection over n finalized contexts with the same reference tables and chromosome map and disjoint
+ * `owned` masks: global strandedness vote, then every table of the others is added into ctxs[root].                */
+int irf_gather(irf_ctx* const* ctxs, uint32_t n, uint32_t root);
 
 /* HBM layout facts for roofline accounting (no upstream counterpart).       */
 typedef struct irf_layout {

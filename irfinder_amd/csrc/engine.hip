@@ -135,6 +135,14 @@ struct irf_ctx {
     uint32_t n_us = 0, n_ue = 0, n_known_dev = 0;
     DevBuf<double> d_out_f64[2];
     DevBuf<uint32_t> d_out_u32[2];
+    // multi-GPU collection (kernels.h: kRowForeign / kRowMine / kRowOrphan per IR row)
+    DevBuf<uint8_t> d_row_code;
+    bool sharded = false;                          // some BAM reference is not owned by this context
+    bool ir_prepared[2] = {false, false};          // foreign rows of the IR table zeroed for an import
+    DevBuf<double> d_tmp_f64;                      // masked copy of an IR table for the export
+    DevBuf<uint32_t> d_tmp_u32;
+    struct ImpJunc { uint32_t chr, left, right, c0, c1; };
+    std::vector<ImpJunc> imp_junc;                 // novel junctions imported from other shards (irf_import_junctions)
 
     // host-side permutations of the reference tables
     uint32_t n_sp = 0, n_roi = 0, n_intron = 0;
@@ -177,6 +185,9 @@ struct irf_ctx {
     int finalize();
     int finalize_directional(int32_t dirn);
     int fetch_results();
+    int export_col(uint32_t what, void* dst, uint64_t* n_out);
+    int import_col(uint32_t what, const void* src, uint64_t n);
+    int own_novel_junctions(std::vector<ImpJunc>& out);
 };
 
 namespace {
@@ -595,6 +606,16 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             TRY(alloc_zero(this, d_out_u32[t], (size_t)n_intron * 6));
         }
     }
+    {
+        std::vector<uint8_t> code(std::max<uint32_t>(n_intron, 1u), (uint8_t)dev::kRowOrphan);
+        for (uint32_t i = 0; i < n_intron; i++) {
+            const uint32_t sl = refchr_slot[ref.in_chr[i]];
+            if (sl < n) code[i] = chr_owned[sl] ? (uint8_t)dev::kRowMine : (uint8_t)dev::kRowForeign;
+        }
+        TRY(upload(this, d_row_code, code));
+        sharded = false;
+        for (uint32_t i = 0; i < n; i++) if (!chr_owned[i]) sharded = true;
+    }
     TRY(alloc_zero(this, d_scalars, 8));
     TRY(alloc_zero(this, d_err, 1));
     {
@@ -624,6 +645,8 @@ int irf_ctx::zero_counters() {
     n_unique = n_events = 0;
     finalized = results_ready = false;
     kj_depth_applied = false;
+    ir_prepared[0] = ir_prepared[1] = false;
+    imp_junc.clear();
     directionality = 0;
     count_events_used = 0;
     memset(&timing, 0, sizeof timing);
@@ -912,6 +935,7 @@ int irf_ctx::finalize_directional(int32_t dirn) {
     if (dirn == directionality) return 0;
     HIP_TRY(hipSetDevice(device));
     directionality = dirn;
+    ir_prepared[1] = false;
     if (dirn != 0) {
         launch_stats(1, dirn);
         HIP_TRY(hipGetLastError());
@@ -946,27 +970,26 @@ int irf_ctx::fetch_results() {
     {
         std::vector<uint32_t> kc((size_t)n_kj * 2, 0u);
         if (n_kj) HIP_TRY(hipMemcpy(kc.data(), d_known_cnt.p, kc.size() * 4, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> uk(n_unique);
-        std::vector<uint32_t> uc(n_unique);
-        if (n_unique) {
-            HIP_TRY(hipMemcpy(uk.data(), d_ukeys.p, n_unique * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(uc.data(), d_ucount.p, n_unique * 4, hipMemcpyDeviceToHost));
+        std::vector<ImpJunc> nov;
+        TRY(own_novel_junctions(nov));
+        if (!imp_junc.empty()) {
+            // novel junctions of other shards (irf_gather / irf_import_junctions): one sorted list, equal coordinates merged
+            nov.insert(nov.end(), imp_junc.begin(), imp_junc.end());
+            std::stable_sort(nov.begin(), nov.end(), [](const ImpJunc& x, const ImpJunc& y) {
+                if (x.chr != y.chr) return x.chr < y.chr;
+                if (x.left != y.left) return x.left < y.left;
+                return x.right < y.right;
+            });
+            size_t w = 0;
+            for (size_t i = 0; i < nov.size(); i++) {
+                if (w && nov[w - 1].chr == nov[i].chr && nov[w - 1].left == nov[i].left && nov[w - 1].right == nov[i].right) {
+                    nov[w - 1].c0 += nov[i].c0; nov[w - 1].c1 += nov[i].c1;
+                } else nov[w++] = nov[i];
+            }
+            nov.resize(w);
         }
         std::vector<uint32_t> oc, ol, orr, c0, c1;
-        uint32_t chr = 0;
-        for (uint64_t u = 0; u < n_unique; u++) {
-            uint64_t gl = uk[u] >> dev::kJuncLeftShift;
-            uint32_t span = (uint32_t)((uk[u] >> 1) & ((1ull << dev::kJuncSpanBits) - 1));
-            uint32_t d = (uint32_t)(uk[u] & 1);
-            while (chr + 1 < n_chr && (!chr_owned[chr] || gl >= chr_base[chr] + ((((uint64_t)chr_len[chr] + 1 + 63) / 64) * 64))) chr++;
-            uint32_t left = (uint32_t)(gl - chr_base[chr]);
-            if (!oc.empty() && oc.back() == chr && ol.back() == left && orr.back() == left + span) {
-                (d ? c1 : c0).back() += uc[u];
-            } else {
-                oc.push_back(chr); ol.push_back(left); orr.push_back(left + span);
-                c0.push_back(d ? 0 : uc[u]); c1.push_back(d ? uc[u] : 0);
-            }
-        }
+        for (const ImpJunc& j : nov) { oc.push_back(j.chr); ol.push_back(j.left); orr.push_back(j.right); c0.push_back(j.c0); c1.push_back(j.c1); }
         h_j_chr.clear(); h_j_left.clear(); h_j_right.clear(); h_j_refdir.clear();
         std::vector<uint32_t> m0, m1;
         size_t a = 0, b = 0, na = oc.size(), nb = kj_left.size();
@@ -1008,6 +1031,111 @@ int irf_ctx::fetch_results() {
         for (uint32_t i = 0; i < n_intron; i++) h_warn[t][i] = (uint8_t)h_u32[t][(size_t)5 * n_intron + i];
     }
     results_ready = true;
+    return 0;
+}
+
+// ---- multi-GPU collection ---------------------------------------------------------------------------------------
+// Copies one result column into caller-owned device memory.  IR tables of a SHARDED context leave with the rows this
+// context does not own zeroed (rows on no BAM reference at all stay with IRF_COL_KEEP_ORPHANS), so that adding the
+// shards' columns (reduce(SUM) over RCCL, irf_import_device, irf_gather) gives the complete table.
+int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
+    if (!n_out) return IRF_E_ARG;
+    if (!finalized) return fail(IRF_E_STATE, "irf_export_device before irf_finalize");
+    const bool keep_orphans = (what_in & IRF_COL_KEEP_ORPHANS) != 0;
+    const uint32_t what = what_in & ~(uint32_t)IRF_COL_KEEP_ORPHANS;
+    const void* src = nullptr;
+    uint64_t n = 0;
+    size_t elem = 4;
+    int table = -1;
+    switch (what) {
+        case IRF_COL_IR_NONDIR_F64: src = d_out_f64[0].p; n = (uint64_t)n_intron * 8; elem = 8; table = 0; break;
+        case IRF_COL_IR_NONDIR_U32: src = d_out_u32[0].p; n = (uint64_t)n_intron * 6; table = 0; break;
+        case IRF_COL_IR_DIR_F64: src = d_out_f64[1].p; n = directionality ? (uint64_t)n_intron * 8 : 0; elem = 8; table = 1; break;
+        case IRF_COL_IR_DIR_U32: src = d_out_u32[1].p; n = directionality ? (uint64_t)n_intron * 6 : 0; table = 1; break;
+        case IRF_COL_JUNC_KEYS: src = d_ukeys.p; n = n_unique; elem = 8; break;
+        case IRF_COL_JUNC_COUNTS: src = d_ucount.p; n = n_unique; break;
+        case IRF_COL_SP_CNT: src = d_sp_cnt.p; n = (uint64_t)n_sp * 2; break;
+        case IRF_COL_ROI_CNT: src = d_roi_cnt.p; n = (uint64_t)n_roi * 2; break;
+        case IRF_COL_CHR_CNT: src = d_chr_cnt.p; n = (uint64_t)n_chr * 2; break;
+        case IRF_COL_KNOWN_CNT: src = d_known_cnt.p; n = (uint64_t)n_kj * 2; break;
+        default: return fail(IRF_E_ARG, "irf_export_device: unknown column");
+    }
+    *n_out = n;
+    if (!dst || !n) return 0;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(dst, src, n * elem, hipMemcpyDeviceToDevice, stream));
+    if (table >= 0 && sharded) {
+        const uint32_t keep = (1u << dev::kRowMine) | (keep_orphans ? (1u << dev::kRowOrphan) : 0u);
+        if (elem == 8) dev::launch_mask_rows_f64((double*)dst, 8, n_intron, d_row_code.p, keep, stream);
+        else dev::launch_mask_rows_u32((uint32_t*)dst, 6, n_intron, d_row_code.p, keep, stream);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// Adds a column another shard exported (and that an RCCL transfer or a peer copy brought to this device) into this
+// context's table.  The first import into an IR table zeroes the rows other shards own (this context computed
+// all-zero-depth rows for them).  Junction key columns cannot be added: their packing depends on the shard's layout
+// (irf_export_junctions / irf_import_junctions carry them as coordinates).
+int irf_ctx::import_col(uint32_t what, const void* src, uint64_t n) {
+    if (!finalized) return fail(IRF_E_STATE, "irf_import_device before irf_finalize");
+    if (!src && n) return fail(IRF_E_ARG, "irf_import_device: null source");
+    HIP_TRY(hipSetDevice(device));
+    uint64_t want = 0;
+    int table = -1;
+    bool f64 = false;
+    void* dstp = nullptr;
+    switch (what) {
+        case IRF_COL_IR_NONDIR_F64: dstp = d_out_f64[0].p; want = (uint64_t)n_intron * 8; f64 = true; table = 0; break;
+        case IRF_COL_IR_NONDIR_U32: dstp = d_out_u32[0].p; want = (uint64_t)n_intron * 6; table = 0; break;
+        case IRF_COL_IR_DIR_F64: dstp = d_out_f64[1].p; want = directionality ? (uint64_t)n_intron * 8 : 0; f64 = true; table = 1; break;
+        case IRF_COL_IR_DIR_U32: dstp = d_out_u32[1].p; want = directionality ? (uint64_t)n_intron * 6 : 0; table = 1; break;
+        case IRF_COL_SP_CNT: dstp = d_sp_cnt.p; want = (uint64_t)n_sp * 2; break;
+        case IRF_COL_ROI_CNT: dstp = d_roi_cnt.p; want = (uint64_t)n_roi * 2; break;
+        case IRF_COL_CHR_CNT: dstp = d_chr_cnt.p; want = (uint64_t)n_chr * 2; break;
+        case IRF_COL_KNOWN_CNT: dstp = d_known_cnt.p; want = (uint64_t)n_kj * 2; break;
+        default: return fail(IRF_E_ARG, "irf_import_device: this column cannot be imported (junction keys: use irf_import_junctions)");
+    }
+    if (n != want) return fail(IRF_E_ARG, "irf_import_device: element count does not match this context's table");
+    if (!n) return 0;
+    if (table >= 0 && !ir_prepared[table]) {
+        const uint32_t keep = (1u << dev::kRowMine) | (1u << dev::kRowOrphan);
+        dev::launch_mask_rows_f64(d_out_f64[table].p, 8, n_intron, d_row_code.p, keep, stream);
+        dev::launch_mask_rows_u32(d_out_u32[table].p, 6, n_intron, d_row_code.p, keep, stream);
+        ir_prepared[table] = true;
+    }
+    if (f64) dev::launch_add_into_f64((double*)dstp, (const double*)src, n, stream);
+    else dev::launch_add_into_u32((uint32_t*)dstp, (const uint32_t*)src, n, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    results_ready = false;
+    return 0;
+}
+
+// This context's novel junctions as coordinates (the packed keys depend on the shard's plane layout), both strands of
+// a junction in one row, sorted by (BAM refID, left, right).
+int irf_ctx::own_novel_junctions(std::vector<ImpJunc>& out) {
+    out.clear();
+    if (!n_unique) return 0;
+    HIP_TRY(hipSetDevice(device));
+    std::vector<uint64_t> uk(n_unique);
+    std::vector<uint32_t> uc(n_unique);
+    HIP_TRY(hipMemcpy(uk.data(), d_ukeys.p, n_unique * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(uc.data(), d_ucount.p, n_unique * 4, hipMemcpyDeviceToHost));
+    uint32_t chr = 0;
+    for (uint64_t u = 0; u < n_unique; u++) {
+        const uint64_t gl = uk[u] >> dev::kJuncLeftShift;
+        const uint32_t span = (uint32_t)((uk[u] >> 1) & ((1ull << dev::kJuncSpanBits) - 1));
+        const uint32_t d = (uint32_t)(uk[u] & 1);
+        while (chr + 1 < n_chr && (!chr_owned[chr] || gl >= chr_base[chr] + ((((uint64_t)chr_len[chr] + 1 + 63) / 64) * 64))) chr++;
+        const uint32_t left = (uint32_t)(gl - chr_base[chr]);
+        if (!out.empty() && out.back().chr == chr && out.back().left == left && out.back().right == left + span) {
+            (d ? out.back().c1 : out.back().c0) += uc[u];
+        } else {
+            out.push_back(ImpJunc{chr, left, left + span, d ? 0u : uc[u], d ? uc[u] : 0u});
+        }
+    }
     return 0;
 }
 
@@ -1204,30 +1332,91 @@ int irf_get_depth(irf_ctx* c, uint32_t chr, uint32_t start, uint32_t end, uint32
     return 0;
 }
 
-int irf_export_device(irf_ctx* c, uint32_t what, void* dst, uint64_t* n_out) {
-    if (!c || !n_out) return IRF_E_ARG;
-    if (!c->finalized) return c->fail(IRF_E_STATE, "irf_export_device before irf_finalize");
-    const void* src = nullptr;
-    uint64_t n = 0;
-    size_t elem = 4;
-    switch (what) {
-        case IRF_COL_IR_NONDIR_F64: src = c->d_out_f64[0].p; n = (uint64_t)c->n_intron * 8; elem = 8; break;
-        case IRF_COL_IR_NONDIR_U32: src = c->d_out_u32[0].p; n = (uint64_t)c->n_intron * 6; break;
-        case IRF_COL_IR_DIR_F64: src = c->d_out_f64[1].p; n = c->directionality ? (uint64_t)c->n_intron * 8 : 0; elem = 8; break;
-        case IRF_COL_IR_DIR_U32: src = c->d_out_u32[1].p; n = c->directionality ? (uint64_t)c->n_intron * 6 : 0; break;
-        case IRF_COL_JUNC_KEYS: src = c->d_ukeys.p; n = c->n_unique; elem = 8; break;
-        case IRF_COL_JUNC_COUNTS: src = c->d_ucount.p; n = c->n_unique; break;
-        case IRF_COL_SP_CNT: src = c->d_sp_cnt.p; n = (uint64_t)c->n_sp * 2; break;
-        case IRF_COL_ROI_CNT: src = c->d_roi_cnt.p; n = (uint64_t)c->n_roi * 2; break;
-        case IRF_COL_CHR_CNT: src = c->d_chr_cnt.p; n = (uint64_t)c->n_chr * 2; break;
-        case IRF_COL_KNOWN_CNT: src = c->d_known_cnt.p; n = (uint64_t)c->n_kj * 2; break;
-        default: return c->fail(IRF_E_ARG, "irf_export_device: unknown column");
+int irf_export_device(irf_ctx* c, uint32_t what, void* dst, uint64_t* n_out) { return c ? c->export_col(what, dst, n_out) : IRF_E_ARG; }
+int irf_import_device(irf_ctx* c, uint32_t what, const void* src, uint64_t n) { return c ? c->import_col(what, src, n) : IRF_E_ARG; }
+
+int irf_export_junctions(irf_ctx* c, uint64_t* n, uint32_t* chr, uint32_t* left, uint32_t* right, uint32_t* cnt_neg, uint32_t* cnt_pos) {
+    if (!c || !n) return IRF_E_ARG;
+    if (!c->finalized) return c->fail(IRF_E_STATE, "irf_export_junctions before irf_finalize");
+    std::vector<irf_ctx::ImpJunc> rows;
+    int rc = c->own_novel_junctions(rows);
+    if (rc != 0) return rc;
+    const uint64_t cap = *n;
+    *n = rows.size();
+    if (!chr && !left && !right && !cnt_neg && !cnt_pos) return 0;          // size query
+    if (!chr || !left || !right || !cnt_neg || !cnt_pos) return c->fail(IRF_E_ARG, "irf_export_junctions: null array");
+    if (cap < rows.size()) return c->fail(IRF_E_RANGE, "irf_export_junctions: arrays too small (*n is the size needed)");
+    for (size_t i = 0; i < rows.size(); i++) {
+        chr[i] = rows[i].chr; left[i] = rows[i].left; right[i] = rows[i].right; cnt_neg[i] = rows[i].c0; cnt_pos[i] = rows[i].c1;
     }
-    *n_out = n;
-    if (!dst || !n) return 0;
-    if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
-    if (hipMemcpyAsync(dst, src, n * elem, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipMemcpy D2D");
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipStreamSynchronize");
+    return 0;
+}
+
+int irf_import_junctions(irf_ctx* c, uint64_t n, const uint32_t* chr, const uint32_t* left, const uint32_t* right, const uint32_t* cnt_neg,
+                         const uint32_t* cnt_pos) {
+    if (!c) return IRF_E_ARG;
+    if (!c->finalized) return c->fail(IRF_E_STATE, "irf_import_junctions before irf_finalize");
+    if (n && (!chr || !left || !right || !cnt_neg || !cnt_pos)) return c->fail(IRF_E_ARG, "irf_import_junctions: null array");
+    for (uint64_t i = 0; i < n; i++) {
+        if (chr[i] >= c->n_chr || right[i] < left[i]) return c->fail(IRF_E_ARG, "irf_import_junctions: row outside the chromosome map");
+        c->imp_junc.push_back(irf_ctx::ImpJunc{chr[i], left[i], right[i], cnt_neg[i], cnt_pos[i]});
+    }
+    c->results_ready = false;
+    return 0;
+}
+
+// In-process collection: one host process drives several contexts (one per GPU, or several on one GPU), each finalized
+// over its own chromosomes.  The strandedness vote is taken over all of them, then every table of the others is added
+// into ctxs[root] (device-to-device copies into a scratch buffer on the root's device, no host round trip except the
+// small novel-junction tables), which afterwards answers irf_get_results / irf_write_outputs for the whole sample.
+int irf_gather(irf_ctx* const* ctxs, uint32_t n, uint32_t root) {
+    if (!ctxs || n == 0 || root >= n) return IRF_E_ARG;
+    for (uint32_t i = 0; i < n; i++) if (!ctxs[i]) return IRF_E_ARG;
+    irf_ctx* R = ctxs[root];
+    for (uint32_t i = 0; i < n; i++) {
+        irf_ctx* c = ctxs[i];
+        if (!c->finalized) return R->fail(IRF_E_STATE, "irf_gather: every context must be finalized");
+        if (c->n_chr != R->n_chr || c->n_intron != R->n_intron || c->n_sp != R->n_sp || c->n_roi != R->n_roi || c->n_kj != R->n_kj)
+            return R->fail(IRF_E_ARG, "irf_gather: contexts with different reference tables or chromosome maps");
+        for (uint32_t k = 0; k < c->n_chr; k++)
+            for (uint32_t j = 0; j < i; j++)
+                if (c->chr_owned[k] && ctxs[j]->chr_owned[k]) return R->fail(IRF_E_ARG, "irf_gather: a BAM reference is owned by two contexts");
+    }
+    // JunctionCount::Directional() over all shards
+    unsigned long long same = 0, opp = 0;
+    for (uint32_t i = 0; i < n; i++) { same += ctxs[i]->votes[0]; opp += ctxs[i]->votes[1]; }
+    int32_t dirn = 0;
+    if (same > opp * (unsigned long long)R->P.dir_ratio) dirn = 1;
+    else if (opp > same * (unsigned long long)R->P.dir_ratio) dirn = -1;
+    for (uint32_t i = 0; i < n; i++) TRY(ctxs[i]->finalize_directional(dirn));
+    static const uint32_t cols[] = {IRF_COL_IR_NONDIR_F64, IRF_COL_IR_NONDIR_U32, IRF_COL_IR_DIR_F64, IRF_COL_IR_DIR_U32,
+                                    IRF_COL_SP_CNT, IRF_COL_ROI_CNT, IRF_COL_CHR_CNT, IRF_COL_KNOWN_CNT};
+    for (uint32_t i = 0; i < n; i++) {
+        if (i == root) continue;
+        irf_ctx* c = ctxs[i];
+        for (uint32_t what : cols) {
+            uint64_t cnt = 0;
+            TRY(c->export_col(what, nullptr, &cnt));
+            if (!cnt) continue;
+            const size_t bytes = cnt * ((what == IRF_COL_IR_NONDIR_F64 || what == IRF_COL_IR_DIR_F64) ? 8 : 4);
+            void* on_peer = nullptr;
+            void* on_root = nullptr;
+            if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&on_peer, bytes) != hipSuccess) return R->fail(IRF_E_NOMEM, "irf_gather: hipMalloc");
+            int rc = c->export_col(what, on_peer, &cnt);
+            if (rc == 0 && (hipSetDevice(R->device) != hipSuccess || hipMalloc(&on_root, bytes) != hipSuccess)) rc = R->fail(IRF_E_NOMEM, "irf_gather: hipMalloc");
+            if (rc == 0 && hipMemcpyPeer(on_root, R->device, on_peer, c->device, bytes) != hipSuccess) rc = R->fail(IRF_E_DEVICE, "irf_gather: hipMemcpyPeer");
+            if (rc == 0) rc = R->import_col(what, on_root, cnt);
+            if (rc == 0 && (hipSetDevice(R->device) != hipSuccess || hipStreamSynchronize(R->stream) != hipSuccess)) rc = R->fail(IRF_E_DEVICE, "irf_gather: synchronize");
+            if (on_root) { (void)hipSetDevice(R->device); (void)hipFree(on_root); }
+            if (on_peer) { (void)hipSetDevice(c->device); (void)hipFree(on_peer); }
+            if (rc != 0) { if (c != R && R->err.empty()) R->err = c->err; return rc; }
+        }
+        std::vector<irf_ctx::ImpJunc> rows;
+        TRY(c->own_novel_junctions(rows));
+        R->imp_junc.insert(R->imp_junc.end(), rows.begin(), rows.end());
+        R->n_fragments += 0;       // (fragments SUBMITTED stay per context: every shard may have been fed the whole sample)
+    }
+    R->results_ready = false;
     return 0;
 }
 

@@ -159,6 +159,15 @@ void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s);
 // known junctions -> SpliceLeft/Right counters + the Directional() vote
 void launch_known_lookups(const JuncLookupTables& J, hipStream_t s);
 
+// ---- multi-GPU collection (gather.hip) ------------------------------------------
+// row code of an intron / table row: 0 = on a BAM reference another shard owns, 1 = on a reference this context owns,
+// 2 = on no BAM reference at all (kept by the root of a gather); rows whose code is not in keep_bits are zeroed
+constexpr uint32_t kRowForeign = 0, kRowMine = 1, kRowOrphan = 2;
+void launch_mask_rows_f64(double* data, uint32_t n_cols, uint64_t n, const uint8_t* code, uint32_t keep_bits, hipStream_t s);
+void launch_mask_rows_u32(uint32_t* data, uint32_t n_cols, uint64_t n, const uint8_t* code, uint32_t keep_bits, hipStream_t s);
+void launch_add_into_f64(double* dst, const double* src, uint64_t n, hipStream_t s);
+void launch_add_into_u32(uint32_t* dst, const uint32_t* src, uint64_t n, hipStream_t s);
+
 // ---- per-intron statistics + IR table --------------------------------------------
 // Everything a row needs besides depth, one 128-byte record per intron.  The kernel keeps a record one dword per lane
 // (stats.hip: header pipeline), so the field order below is its ABI: dword index in the comment.

@@ -81,6 +81,10 @@ def lib():
     L.irf_get_depth.argtypes = [vp, u32, u32, u32, u32, C.c_void_p]
     L.irf_reset.argtypes = [vp]
     L.irf_export_device.argtypes = [vp, u32, C.c_void_p, C.POINTER(u64)]
+    L.irf_import_device.argtypes = [vp, u32, C.c_void_p, u64]
+    L.irf_export_junctions.argtypes = [vp, C.POINTER(u64)] + [C.c_void_p] * 5
+    L.irf_import_junctions.argtypes = [vp, u64] + [C.c_void_p] * 5
+    L.irf_gather.argtypes = [C.POINTER(vp), u32, u32]
     L.irf_get_timing.argtypes = [vp, C.POINTER(IrfTiming)]
     L.irf_get_layout.argtypes = [vp, C.POINTER(IrfLayout)]
     L.irf_reader_create.argtypes = [C.POINTER(IrfParams), C.POINTER(vp)]
@@ -465,6 +469,23 @@ class Engine:
         self._chk(self.L.irf_export_device(self.h, what, C.c_void_p(dst_ptr), C.byref(n)))
         return n.value
 
+    def import_device(self, what, src_ptr, n):
+        """irf_import_device: add a column another shard exported (already on this device) into this context's table."""
+        self._chk(self.L.irf_import_device(self.h, what, C.c_void_p(src_ptr), int(n)))
+
+    def export_junctions(self):
+        """This context's novel junctions as coordinates: dict of uint32 arrays chr, left, right, cnt_neg, cnt_pos."""
+        n = C.c_uint64(0)
+        self._chk(self.L.irf_export_junctions(self.h, C.byref(n), None, None, None, None, None))
+        a = [np.zeros(n.value, np.uint32) for _ in range(5)]
+        if n.value:
+            self._chk(self.L.irf_export_junctions(self.h, C.byref(n), *[x.ctypes.data for x in a]))
+        return dict(zip(("chr", "left", "right", "cnt_neg", "cnt_pos"), a))
+
+    def import_junctions(self, rows):
+        a = [np.ascontiguousarray(rows[k], np.uint32) for k in ("chr", "left", "right", "cnt_neg", "cnt_pos")]
+        self._chk(self.L.irf_import_junctions(self.h, len(a[0]), *[x.ctypes.data for x in a]))
+
     def close(self):
         if self.h:
             self.L.irf_destroy(self.h)
@@ -475,6 +496,15 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def gather(engines, root=0):
+    """irf_gather: in-process collection over finalized engines with disjoint `owned` masks into engines[root]."""
+    L = lib()
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    rc = L.irf_gather(arr, len(engines), int(root))
+    if rc != 0:
+        raise IrfError(rc, L.irf_last_error(engines[root].h).decode())
 
 
 def device_batch(tensors, n_frag, n_blk):

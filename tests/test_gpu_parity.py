@@ -394,6 +394,57 @@ def test_chromosome_shards_sum_to_the_whole_P3():
     assert res[0]["n_fragments"] == res[1]["n_fragments"] == batch.n_frag       # submitted, not counted
 
 
+def test_irf_gather_collects_shards_into_the_root_context(tmp_path):
+    """irf_gather (the C ABI's in-process multi-GPU collection): three contexts with disjoint `owned` masks, each fed
+    the whole sample; afterwards the ROOT context's results and its six text files equal the single-context run's —
+    novel junctions (half of ref-sj.ref withheld), an intron on a chromosome no BAM reference names (nobody's row: the
+    root keeps it) and the global strandedness vote included."""
+    from irfinder_amd import distributed as irfdist
+    ann, sim = small_world(seed=23, stranded=True, n_chr=5)
+    names, lens, batch = read_batch(sim.bam(0, 30000))
+    cover = ann.cover_bed + "chrNowhere\t10\t500\tQ/E/+/1/10/500/clean\t0\t+\t10\t500\t0\t1\t490\t0\n"
+    sj = "".join(l for i, l in enumerate(ann.sj_ref.splitlines(True)) if i % 2 == 0)
+    refs = (cover, sj, ann.read_continues_ref, ann.roi_bed)
+    e, whole = run_gpu(refs, names, lens, [batch])
+    os.makedirs(tmp_path / "whole")
+    e.write_outputs(str(tmp_path / "whole"))
+    for root in (0, 2):
+        masks = irfdist.shard_chromosomes(lens, 3)
+        engs = []
+        for m in masks:
+            ei = engine.Engine(engine.RefTables.from_texts(refs))
+            ei.chr_map_update(names, lens, m)
+            ei.process(batch)
+            ei.finalize()
+            engs.append(ei)
+        engine.gather(engs, root=root)
+        got = engs[root].results()
+        assert_results_equal(got, whole, rel=0.0, what="gathered into root %d" % root)
+        novel = (got["junc_refdir"] == 0) & (got["junc_cnt"].sum(axis=0) > 0)
+        assert novel.sum() > 20 and got["has_dir"]
+        out = tmp_path / ("g%d" % root)
+        os.makedirs(out)
+        engs[root].write_outputs(str(out))
+        for f in sorted(os.listdir(tmp_path / "whole")):
+            assert filecmp.cmp(out / f, tmp_path / "whole" / f, shallow=False), f
+    # the pieces of the recipe for one process per GPU: export (masked rows) -> add -> import, junction rows as coordinates
+    import torch
+    from irfinder_amd._abi import COL_IR_NONDIR_F64, COL_KEEP_ORPHANS
+    a, b = engs[0], engs[1]          # (a was a root above: its tables are complete; b still holds only its own rows)
+    n = b.export_size(COL_IR_NONDIR_F64)
+    t = torch.empty(n, dtype=torch.float64, device="cuda")
+    b.export_device(COL_IR_NONDIR_F64, t.data_ptr())
+    name_to_idx = {nm: i for i, nm in enumerate(names)}
+    in_chr = [name_to_idx.get(l.split("\t", 1)[0], -1) for l in cover.splitlines()]
+    mine = np.array([c >= 0 and masks[1][c] == 1 for c in in_chr])
+    tt = t.view(8, -1).cpu().numpy()
+    assert np.all(tt[:, ~mine] == 0) and np.array_equal(tt[1, mine], whole["nondir"]["intron_depth"][mine])
+    rows = b.export_junctions()
+    assert len(rows["chr"]) > 0 and set(rows["chr"].tolist()) <= set(np.nonzero(masks[1])[0].tolist())
+    with pytest.raises(engine.IrfError):
+        b.import_device(COL_IR_NONDIR_F64, t.data_ptr(), n - 1)          # wrong element count
+
+
 def test_chr22_scale_matches_oracle_and_properties():
     """BASELINE configs[0] shape (2 M simulated 2x100 pairs, chr22-sized reference, unstranded) — the largest size the
     oracle finishes in seconds — bit-exact, plus the size-independent properties used at the full bench size:
