@@ -218,6 +218,44 @@ def test_device_reader_record_payload_that_looks_like_records():
         assert 1 <= d.timing()["chain_rounds"] < 200            # reported: rounds beyond 2-3 mean the speculation was fooled
 
 
+def test_four_samples_streamed_through_one_context_with_overlapped_reading():
+    """BASELINE configs[4] shape at test size: four different BAMs (same reference) through ONE context, irf_reset
+    between them, the device reader of sample k+1 running on a second host thread under the count / finalize of sample
+    k; every sample's tables equal the oracle's on that sample's bytes."""
+    from concurrent.futures import ThreadPoolExecutor
+    from util import assert_results_equal
+    ann, sim = small_world(seed=31, stranded=True)
+    bams = [sim.bam(20000 * k, 9000 + 1000 * k) for k in range(4)]          # different reads, different sizes
+    zs = [bgzf_compress(b, block=0x3000) for b in bams]
+    eng = engine.Engine(engine.RefTables.from_texts(ann.ref_texts()))
+
+    def read_sample(k):
+        d = engine.DeviceReader()
+        d.feed(zs[k])
+        d.finish()
+        return d, d.batch_struct(), d.header()
+
+    with ThreadPoolExecutor(1) as ex:
+        fut = ex.submit(read_sample, 0)
+        for k in range(4):
+            d, b, (names, lens) = fut.result()
+            if k + 1 < 4:
+                fut = ex.submit(read_sample, k + 1)
+            if k == 0:
+                eng.chr_map_update(names, lens)
+            else:
+                eng.reset()
+            eng.submit(b)
+            eng.finalize()
+            got = eng.results()
+            d.close()
+            o = orc.Oracle(ann.ref_texts())
+            o.process_bam(bams[k])
+            o.finalize()
+            assert_results_equal(got, o.results(), rel=0.0, what="sample %d" % k)
+            assert got["n_fragments"] > 8000
+
+
 def test_device_reader_fault_injection():
     ann, sim = small_world(seed=5)
     bam = sim.bam(0, 2000)
