@@ -181,7 +181,7 @@ struct irf_ctx {
     int ensure_junc_capacity(uint64_t need);
     int submit(const irf_batch* b, uint64_t* id);
     int wait(uint64_t id);
-    void launch_stats(int t, int dirn);
+    void launch_stats(int t, int dirn, bool dual = false);
     int finalize();
     int finalize_directional(int32_t dirn);
     int fetch_results();
@@ -788,7 +788,8 @@ int irf_ctx::wait(uint64_t id) {
 }
 
 // one IR table: t = 0 non-directional (both strands), t = 1 directional under `dirn`
-void irf_ctx::launch_stats(int t, int dirn) {
+// (dual: both tables in one pass over the planes — table 0 into d_out_*[0], the directional one into d_out_*[1])
+void irf_ctx::launch_stats(int t, int dirn, bool dual) {
     dev::IntronTables T;
     memset(&T, 0, sizeof T);
     T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
@@ -805,6 +806,8 @@ void irf_ctx::launch_stats(int t, int dirn) {
     T.warn_minor_ratio = P.warn_minor_ratio; T.warn_nonuniform_rel = P.warn_nonuniform_rel;
     T.warn_nonuniform_abs = P.warn_nonuniform_abs; T.warn_nonuniform_and = P.warn_nonuniform_and;
     T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
+    T.dual = dual ? 1u : 0u;
+    if (dual) { T.out_f64 = d_out_f64[0].p; T.out_u32 = d_out_u32[0].p; T.out_f64_b = d_out_f64[1].p; T.out_u32_b = d_out_u32[1].p; }
     dev::launch_intron_stats(T, stats_classes, stream);
 }
 
@@ -903,8 +906,8 @@ int irf_ctx::finalize() {
     if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
     else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
     // ---- per-intron statistics and IR rows ----
-    launch_stats(0, 0);
-    if (directionality != 0) launch_stats(1, directionality);
+    if (directionality != 0) launch_stats(0, directionality, true);      // both IR tables from one pass over the planes
+    else launch_stats(0, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], stream));
     HIP_TRY(hipStreamSynchronize(stream));

@@ -254,6 +254,11 @@ struct IntronTables {
     // outputs
     double* out_f64;               // [8][n_intron]
     uint32_t* out_u32;             // [6][n_intron]  (5 counts + warning)
+    // dual = 1: ONE pass computes the non-directional table into out_* and the directional one (under `directionality`,
+    // which must be non-zero) into out_*_b; dual = 0: one table, non-directional if directionality == 0
+    uint32_t dual;
+    double* out_f64_b;
+    uint32_t* out_u32_b;
     uint32_t* err_flags;
 };
 void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s);

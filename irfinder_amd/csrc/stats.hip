@@ -59,6 +59,9 @@ namespace {
 #ifndef STATS_BITS_SMALL
 #define STATS_BITS_SMALL 10
 #endif
+#ifndef STATS_MIN_WAVES_DUAL
+#define STATS_MIN_WAVES_DUAL 6      // (4 = 128 registers, no spills: measured slower, 3.37 vs 3.17 ms on configs[2])
+#endif
 constexpr int kQueries = 8;
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 constexpr uint32_t kMaxBlk = 64;    // measured blocks per descriptor chunk: one per lane
@@ -273,18 +276,21 @@ __device__ __forceinline__ double percentile_value(const PctRanks& q, uint32_t v
     return vk + ((double)q.rem / 100.0) * ((double)vb - vk);
 }
 
-template <int kThreads, int kMaxFlank, int kInFlight, int kBinBits>
-__global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel(IntronTables T, const uint32_t* __restrict__ wg_off, uint32_t prof_slot) {
+// kTables = 2: the non-directional AND the directional table in ONE pass over the planes (both strands are loaded for
+// the first anyway; the second takes the intron's own strand out of the same registers): two histograms, two sets of
+// flank windows, then medians / rank queries / row once per table.  kTables = 1: one table, T.directionality selects it.
+template <int kThreads, int kMaxFlank, int kInFlight, int kBinBits, int kTables>
+__global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : STATS_MIN_WAVES)) void intron_stats_kernel(IntronTables T, const uint32_t* __restrict__ wg_off, uint32_t prof_slot) {
     constexpr int kWaves = kThreads / 64;
     constexpr int kBins = 1 << kBinBits;                   // histogram bins per level of the rank select
     constexpr int kBinsPerThread = kBins / kThreads;
     static_assert(kBinsPerThread >= 1 && kBinsPerThread <= 16, "a thread's bins must fit one DPP row");
-    __shared__ __align__(16) uint32_t s_cnt[kBins];
-    __shared__ uint32_t s_win[2][kMaxFlank];               // depths of the two flank windows
+    __shared__ __align__(16) uint32_t s_cnt[kTables * kBins];
+    __shared__ uint32_t s_win[kTables][2][kMaxFlank];      // depths of the two flank windows, per table
     __shared__ uint32_t s_med[4];                          // per window: the two order statistics its median reads
     __shared__ uint32_t s_wc[kWaves];
     __shared__ unsigned long long s_ws[kWaves];
-    __shared__ uint32_t s_max, s_overflow, s_sel_bin, s_sel_cnt;
+    __shared__ uint32_t s_max, s_overflow[kTables], s_sel_bin, s_sel_cnt;
     __shared__ unsigned long long s_total, s_nz, s_acc;
     __shared__ uint32_t s_qval[kQueries];
     __shared__ unsigned long long s_qsum[kQueries];
@@ -351,9 +357,12 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
     const uint32_t qneed = (r_flags >> 8) & 0xffu;
     const bool r_valid = (r_flags & 1u) != 0;
     const bool valid = r_valid && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
-    C.plane = 2;
-    if (T.directionality != 0) C.plane = (((r_flags & 2u) != 0) == (T.directionality > 0)) ? 1 : 0;
-    const int plane = C.plane;
+    // the plane(s) a table reads: 2 = both strands (non-directional), else the intron's own strand under the vote
+    const int plane_strand = (((r_flags & 2u) != 0) == (T.directionality > 0)) ? 1 : 0;
+    int planes[kTables];
+    if (kTables == 2) { planes[0] = 2; planes[kTables - 1] = plane_strand; }
+    else planes[0] = T.directionality != 0 ? plane_strand : 2;
+    C.plane = kTables == 2 ? 2 : planes[0];                  // what the main pass loads
 
     // first / last flank_len nt of the intron, flank_offset nt inside it (full coordinates)
     uint64_t w0[2], w1[2];
@@ -366,8 +375,9 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
         w0[1] = gE - (fo + fl < ilen ? fo + fl : ilen);
     }
 
-    for (int k = tid; k < kBins / 4; k += kThreads) reinterpret_cast<uint4*>(s_cnt)[k] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) { s_max = 0; s_overflow = 0; s_total = 0; s_nz = 0; s_acc = 0; }
+    for (int k = tid; k < kTables * kBins / 4; k += kThreads) reinterpret_cast<uint4*>(s_cnt)[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < kTables) s_overflow[tid] = 0;
+    if (tid == 0) { s_max = 0; s_total = 0; s_nz = 0; s_acc = 0; }
     if (tid < 4) s_med[tid] = 0;
     if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
     __syncthreads();
@@ -377,15 +387,22 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
     // (total, non-zero count and maximum are read off the histogram afterwards)
     uint32_t nwin[2] = {0, 0};
     if (valid) {
-        bool ovf = false;
+        bool ovf[kTables];
+#pragma unroll
+        for (int t = 0; t < kTables; t++) ovf[t] = false;
         if (!T.flank_use_measured) {
             // raw-coordinate windows: the engine keeps the buckets under them, contiguous in the plane
             for (int wi = 0; wi < 2; wi++) {
                 if (w0[wi] >= w1[wi]) continue;
                 const uint64_t len = w1[wi] - w0[wi];
                 const uint64_t cs = plane_coord(T.pmap, w0[wi]);
-                uint32_t* dst = s_win[wi];
-                for_each_depth<kWaves>(C, cs, cs + len, [&](uint64_t x, uint32_t v, bool ok) { if (ok) dst[(uint32_t)(x - cs)] = v; });
+#pragma unroll
+                for (int t = 0; t < kTables; t++) {
+                    Ctx Cw = C;
+                    Cw.plane = planes[t];
+                    uint32_t* dst = s_win[t][wi];
+                    for_each_depth<kWaves>(Cw, cs, cs + len, [&](uint64_t x, uint32_t v, bool ok) { if (ok) dst[(uint32_t)(x - cs)] = v; });
+                }
                 nwin[wi] = (uint32_t)len;
             }
         }
@@ -436,8 +453,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
 #pragma unroll
                 for (int j = 0; j < kInFlight; j++) {
                     if (s0 + j * kWaves >= S) continue;                // wave-uniform
-                    const Seg sgj = combine_seg(raw[j]);
-                    if (T.ablate & 4u) { if (sgj.a.x + sgj.a.y + sgj.a.z + sgj.a.w + (int)sgj.carry == 0x7fffffff) ovf = true; continue; }     // diagnostic: loads only
+                    if (T.ablate & 4u) { const Seg sgj = combine_seg(raw[j]); if (sgj.a.x + sgj.a.y + sgj.a.z + sgj.a.w + (int)sgj.carry == 0x7fffffff) ovf[0] = true; continue; }     // diagnostic: loads only
                     // everything wave-uniform about the segment, relative to its first position (scalar unit): the
                     // measured part [lo, hi) and the parts of the two flank windows, [wl, wh) with element index
                     // wat + (p - wa) in the window buffer
@@ -461,57 +477,67 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
                         wat[wi] = lane_u32(d_wat[wi], b);
                     }
                     const bool win_here = wl[0] < wh[0] || wl[1] < wh[1];
-                    // depths of this lane's four positions
-                    const uint32_t t = (uint32_t)(sgj.a.x + sgj.a.y + sgj.a.z + sgj.a.w);
-                    const uint32_t incl = wave_inclusive_scan_dpp(t);
-                    const uint32_t v0 = sgj.carry + incl - t + (uint32_t)sgj.a.x;
-                    const uint32_t v1 = v0 + (uint32_t)sgj.a.y, v2 = v1 + (uint32_t)sgj.a.z, v3 = v2 + (uint32_t)sgj.a.w;
                     const int32_t p0 = (int32_t)(lane * 4u);
-                    // Depth is piecewise constant.  A lane whose four positions are all measured and equal ("full") is
-                    // one histogram entry of weight 4; full lanes are merged per value by the wave (two rounds of
-                    // leader election: a segment rarely holds more than two frequent depths), the rest add on their own.
-                    const bool full = v1 == v0 && v2 == v0 && v3 == v0 && p0 >= lo && p0 + 3 < hi;
-                    uint64_t todo = __ballot(full);
-                    bool pending = full;
 #pragma unroll
-                    for (int round = 0; round < 2; round++) {
-                        if (!todo) break;                                  // wave-uniform
-                        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-                        const uint32_t lead = lane_u32(v0, leader);
-                        const uint64_t same = __ballot(pending && v0 == lead);
-                        if (lead < (uint32_t)kBins) { if (lane == leader) atomicAdd(&s_cnt[lead], 4u * (uint32_t)__popcll(same)); }
-                        else ovf = true;
-                        pending = pending && v0 != lead;
-                        todo &= ~same;
-                    }
-                    if (todo) {
-                        if (pending) { if (v0 < (uint32_t)kBins) atomicAdd(&s_cnt[v0], 4u); else ovf = true; }
-                    }
-                    if (__ballot(!full)) {
-                        // lanes on a depth change or on the edge of the measured part: position by position
-                        const uint32_t vv[4] = {v0, v1, v2, v3};
+                    for (int t = 0; t < kTables; t++) {
+                        // the series of this table: both strands added (the prefix is linear), or the intron's own strand
+                        Seg sgj;
+                        if (kTables == 1 || t == 0) sgj = combine_seg(raw[j]);
+                        else if (plane_strand == 1) { sgj.a = raw[j].v; sgj.carry = raw[j].cv; }
+                        else { sgj.a = raw[j].u; sgj.carry = raw[j].cu; }
+                        uint32_t* const cnt = s_cnt + t * kBins;
+                        // depths of this lane's four positions
+                        const uint32_t tt = (uint32_t)(sgj.a.x + sgj.a.y + sgj.a.z + sgj.a.w);
+                        const uint32_t incl = wave_inclusive_scan_dpp(tt);
+                        const uint32_t v0 = sgj.carry + incl - tt + (uint32_t)sgj.a.x;
+                        const uint32_t v1 = v0 + (uint32_t)sgj.a.y, v2 = v1 + (uint32_t)sgj.a.z, v3 = v2 + (uint32_t)sgj.a.w;
+                        // Depth is piecewise constant.  A lane whose four positions are all measured and equal ("full") is
+                        // one histogram entry of weight 4; full lanes are merged per value by the wave (two rounds of
+                        // leader election: a segment rarely holds more than two frequent depths), the rest add on their own.
+                        const bool full = v1 == v0 && v2 == v0 && v3 == v0 && p0 >= lo && p0 + 3 < hi;
+                        uint64_t todo = __ballot(full);
+                        bool pending = full;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            if (!full && p0 + q >= lo && p0 + q < hi) { if (vv[q] < (uint32_t)kBins) atomicAdd(&s_cnt[vv[q]], 1u); else ovf = true; }
+                        for (int round = 0; round < 2; round++) {
+                            if (!todo) break;                                  // wave-uniform
+                            const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+                            const uint32_t lead = lane_u32(v0, leader);
+                            const uint64_t same = __ballot(pending && v0 == lead);
+                            if (lead < (uint32_t)kBins) { if (lane == leader) atomicAdd(&cnt[lead], 4u * (uint32_t)__popcll(same)); }
+                            else ovf[t] = true;
+                            pending = pending && v0 != lead;
+                            todo &= ~same;
                         }
-                    }
-                    if (win_here) {
-                        const uint32_t vv[4] = {v0, v1, v2, v3};
+                        if (todo) {
+                            if (pending) { if (v0 < (uint32_t)kBins) atomicAdd(&cnt[v0], 4u); else ovf[t] = true; }
+                        }
+                        if (__ballot(!full)) {
+                            // lanes on a depth change or on the edge of the measured part: position by position
+                            const uint32_t vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int32_t pq = p0 + q;
-                            if (pq >= wl[0] && pq < wh[0]) s_win[0][wat[0] + (uint32_t)(pq - wa[0])] = vv[q];
-                            if (pq >= wl[1] && pq < wh[1]) s_win[1][wat[1] + (uint32_t)(pq - wa[1])] = vv[q];
+                            for (int q = 0; q < 4; q++) {
+                                if (!full && p0 + q >= lo && p0 + q < hi) { if (vv[q] < (uint32_t)kBins) atomicAdd(&cnt[vv[q]], 1u); else ovf[t] = true; }
+                            }
+                        }
+                        if (win_here) {
+                            const uint32_t vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int32_t pq = p0 + q;
+                                if (pq >= wl[0] && pq < wh[0]) s_win[t][0][wat[0] + (uint32_t)(pq - wa[0])] = vv[q];
+                                if (pq >= wl[1] && pq < wh[1]) s_win[t][1][wat[1] + (uint32_t)(pq - wa[1])] = vv[q];
+                            }
                         }
                     }
                 }
             }
         }
-        if (ovf) s_overflow = 1;
+#pragma unroll
+        for (int t = 0; t < kTables; t++) if (ovf[t]) s_overflow[t] = 1;
         PROF_MARK(1);
     } else {
         // all-zero depth: N zeros in the histogram, all-zero windows of the right size
-        if (tid == 0) s_cnt[0] = (uint32_t)N;
+        if (tid < kTables) s_cnt[tid * kBins] = (uint32_t)N;
         for (int wi = 0; wi < 2; wi++) {
             uint32_t n = 0;
             if (w0[wi] < w1[wi]) {
@@ -525,13 +551,27 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
                     n = (uint32_t)(w1[wi] - w0[wi]);
                 }
             }
-            for (uint32_t k = tid; k < n; k += kThreads) s_win[wi][k] = 0;
+            for (uint32_t k = tid; k < n; k += kThreads) { s_win[0][wi][k] = 0; s_win[kTables - 1][wi][k] = 0; }
             nwin[wi] = n;
         }
     }
     __syncthreads();
     PROF_MARK(2);
-    const bool overflow = s_overflow != 0;
+    // ---------------- per table: medians, rank queries, the row ----------------
+#pragma unroll
+    for (int t = 0; t < kTables; t++) {
+    if (t > 0) {            // the per-table results of the table before were consumed by its row (barrier at its end)
+        if (tid == 0) { s_max = 0; s_total = 0; s_nz = 0; s_acc = 0; }
+        if (tid < 4) s_med[tid] = 0;
+        if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
+        __syncthreads();
+    }
+    uint32_t* const cnt = s_cnt + t * kBins;
+    const int plane = planes[t];
+    C.plane = plane;
+    double* const out_f64 = t == 0 ? T.out_f64 : T.out_f64_b;
+    uint32_t* const out_u32 = t == 0 ? T.out_u32 : T.out_u32_b;
+    const bool overflow = s_overflow[t] != 0;
     if (overflow) {
         // depth beyond the single-level histogram somewhere: maximum, total and non-zero count by a pass of their own
         uint32_t vmax = 0;
@@ -551,7 +591,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
         }
         if (lane == 0) { atomicMax(&s_max, vmax); atomicAdd(&s_total, tsum); atomicAdd(&s_nz, nz); }
     } else if (tid == 0) {
-        s_nz = N - s_cnt[0];
+        s_nz = N - cnt[0];
     }
 
     // ---------------- flank medians: rank of every window element by counting ----------------
@@ -566,7 +606,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
             if ((int)wave != (wi ? wi1_wave : 0)) continue;
             const uint32_t n = nwin[wi];
             if (n == 0u) continue;
-            const uint32_t v = lane < n ? s_win[wi][lane] : 0u;
+            const uint32_t v = lane < n ? s_win[t][wi][lane] : 0u;
             const uint64_t cand = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
             const int nbits = 32 - __clz((int)(wave_or_dpp(v) | 1u));
             const uint32_t va = wave_kth(v, cand, (uint32_t)fq[wi].ra, nbits);
@@ -577,7 +617,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
         const uint32_t n0 = nwin[0], n1 = nwin[1];
         for (uint32_t e = tid; e < n0 + n1; e += kThreads) {
             const int wi = e >= n0 ? 1 : 0;
-            const uint32_t* w = s_win[wi];
+            const uint32_t* w = s_win[t][wi];
             const uint32_t n = wi ? n1 : n0, idx = wi ? e - n0 : e;
             const uint32_t v = w[idx];
             uint32_t r = 0;
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
         unsigned long long tsum = 0;
 #pragma unroll
         for (int j = 0; j < kBinsPerThread; j++) {
-            c[j] = s_cnt[tid * kBinsPerThread + j];
+            c[j] = cnt[tid * kBinsPerThread + j];
             tot += c[j];
             tsum += (unsigned long long)c[j] * (unsigned long long)(tid * kBinsPerThread + j);
         }
@@ -627,7 +667,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
             const unsigned long long o_psum = lane_u64(pre_sum, ol);
             const uint32_t base = (wave * 64u + ol) * (uint32_t)kBinsPerThread;    // the owner's first bin
             const bool mine = lane < (uint32_t)kBinsPerThread;
-            const uint32_t cj = mine ? s_cnt[base + lane] : 0u;
+            const uint32_t cj = mine ? cnt[base + lane] : 0u;
             const uint32_t wj = cj * lane;                                         // (bin - base) * count: N < 2^28 (host check)
             const uint32_t ic = row_inclusive_scan_dpp(cj), iw = row_inclusive_scan_dpp(wj);
             const uint64_t hit = __ballot(mine && rr >= ic - cj && rr < ic);       // exactly one lane
@@ -652,13 +692,13 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
             uint32_t prefix = 0;
             for (int lv = 0; lv < levels; lv++) {
                 const int shift = kBinBits * (levels - 1 - lv);
-                for (int k = tid; k < kBins; k += kThreads) s_cnt[k] = 0;
+                for (int k = tid; k < kBins; k += kThreads) cnt[k] = 0;
                 __syncthreads();
                 for (uint32_t b = b0; b < b0 + nb; b++) {
                     const uint64_t bc = T.blks[b].cstart;
                     for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
                         const bool in = ok && (lv == 0 || (v >> (shift + kBinBits)) == prefix);
-                        if (in) atomicAdd(&s_cnt[(v >> shift) & (uint32_t)(kBins - 1)], 1u);
+                        if (in) atomicAdd(&cnt[(v >> shift) & (uint32_t)(kBins - 1)], 1u);
                     });
                 }
                 __syncthreads();
@@ -666,7 +706,7 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
                 uint32_t tot = 0;
 #pragma unroll
                 for (int j = 0; j < kBinsPerThread; j++) {
-                    c[j] = s_cnt[tid * kBinsPerThread + j];
+                    c[j] = cnt[tid * kBinsPerThread + j];
                     tot += c[j];
                 }
                 uint32_t pre;
@@ -767,22 +807,23 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
         else warn = 0;
         const uint64_t n = T.n_intron;
         const uint64_t i = r_row;
-        T.out_f64[0 * n + i] = coverage;
-        T.out_f64[1 * n + i] = depth;
-        T.out_f64[2 * n + i] = pv[0];
-        T.out_f64[3 * n + i] = pv[1];
-        T.out_f64[4 * n + i] = pv[2];
-        T.out_f64[5 * n + i] = flank0;
-        T.out_f64[6 * n + i] = flank1;
-        T.out_f64[7 * n + i] = irratio;
-        T.out_u32[0 * n + i] = spl;
-        T.out_u32[1 * n + i] = spr;
-        T.out_u32[2 * n + i] = jl;
-        T.out_u32[3 * n + i] = jr;
-        T.out_u32[4 * n + i] = je;
-        T.out_u32[5 * n + i] = warn;
+        out_f64[0 * n + i] = coverage;
+        out_f64[1 * n + i] = depth;
+        out_f64[2 * n + i] = pv[0];
+        out_f64[3 * n + i] = pv[1];
+        out_f64[4 * n + i] = pv[2];
+        out_f64[5 * n + i] = flank0;
+        out_f64[6 * n + i] = flank1;
+        out_f64[7 * n + i] = irratio;
+        out_u32[0 * n + i] = spl;
+        out_u32[1 * n + i] = spr;
+        out_u32[2 * n + i] = jl;
+        out_u32[3 * n + i] = jr;
+        out_u32[4 * n + i] = je;
+        out_u32[5 * n + i] = warn;
     }
-    __syncthreads();            // the row has read the LDS results: the next intron may clear them
+    __syncthreads();            // the row has read the LDS results: the next table / intron may clear them
+    }       // tables
     PROF_MARK(5);
     recA = recB; recB = recC; dA = dB; tcA = tcB;
     }
@@ -800,8 +841,13 @@ __global__ __launch_bounds__(kThreads, STATS_MIN_WAVES) void intron_stats_kernel
 // walks records [wg_off[c][w], wg_off[c][w + 1]) (the host balanced the lists).  The 64-thread class keeps its flank
 // windows in a 64-entry LDS buffer: the host puts every intron into the 256-thread class when flank_len is larger.
 void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s) {
-    if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
-    if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+    if (T.dual) {       // both tables in one pass (T.directionality != 0; outputs out_* and out_*_b)
+        if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10, 2>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
+        if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL, 2>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+    } else {
+        if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10, 1>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
+        if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL, 1>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+    }
 #ifdef STATS_PROF
     {
         static std::vector<uint32_t> h((size_t)kProfMax * 8);
