@@ -70,7 +70,7 @@ def main():
     from irfinder_amd import distributed as irfdist
     from irfinder_amd import engine
     from irfinder_amd._abi import (COL_IR_NONDIR_F64, COL_IR_NONDIR_U32, COL_IR_DIR_F64, COL_IR_DIR_U32, COL_JUNC_KEYS,
-                                   COL_JUNC_COUNTS, COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, COL_KNOWN_CNT, COL_KEEP_ORPHANS, Batch)
+                                   COL_JUNC_COUNTS, COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, COL_KNOWN_CNT, COL_KEEP_ORPHANS, COL_NO_SYNC, Batch)
     from irfinder_amd.synth import world as synth_world
     from irfinder_amd.synth.annotation import GRCH38, make_annotation, small_chroms
     from irfinder_amd.synth.reads import ReadSimulator
@@ -181,35 +181,59 @@ def main():
         if world > 1:       # the strandedness vote is global: one all-reduce of two integers
             v = torch.tensor(eng.votes(), dtype=torch.int64, device=coll_dev)
             eng.finalize_directional(irfdist.global_directionality(v, dist, eng.params.dir_ratio))
-        tabs = {
-            "ir_f64": export(COL_IR_NONDIR_F64, (8, n_in), torch.float64),
-            "ir_u32": export(COL_IR_NONDIR_U32, (6, n_in), torch.int32),
-            "sp_cnt": export(COL_SP_CNT, None, torch.int32),
-            "roi_cnt": export(COL_ROI_CNT, None, torch.int32),
-            "chr_cnt": export(COL_CHR_CNT, None, torch.int32),
-            "known_cnt": export(COL_KNOWN_CNT, None, torch.int32),
-            "junc_keys": export(COL_JUNC_KEYS, None, torch.int64),
-            "junc_counts": export(COL_JUNC_COUNTS, None, torch.int32),
-        }
-        if eng.export_size(COL_IR_DIR_F64):
-            tabs["ir_dir_f64"] = export(COL_IR_DIR_F64, (8, n_in), torch.float64)
-            tabs["ir_dir_u32"] = export(COL_IR_DIR_U32, (6, n_in), torch.int32)
-        if world > 1:
-            if coll_dev.type == "cpu":
-                tabs = {k: t.cpu() for k, t in tabs.items()}
-            got = irfdist.gather_tables(tabs, dist)
-        else:
-            got = irfdist.gather_tables(tabs, None)
-        torch.cuda.synchronize()
-        t_d = time.perf_counter()
-        if rank == 0:       # the IR table lands in page-locked host memory
+        if world == 1:
+            # one GPU: the IR tables go straight into page-locked host memory (one PCIe crossing, no device-side copy), the
+            # small tables into device buffers; every copy is only queued (IRF_COL_NO_SYNC), one wait for all of them
             if "ir_f64" not in out:
                 out["ir_f64"] = torch.empty((8, n_in), dtype=torch.float64, pin_memory=True)
                 out["ir_u32"] = torch.empty((6, n_in), dtype=torch.int32, pin_memory=True)
-            out["ir_f64"].copy_(got["ir_f64"], non_blocking=True)
-            out["ir_u32"].copy_(got["ir_u32"], non_blocking=True)
+                out["ir_dir_f64"] = torch.empty((8, n_in), dtype=torch.float64, pin_memory=True)
+                out["ir_dir_u32"] = torch.empty((6, n_in), dtype=torch.int32, pin_memory=True)
+            tabs = {}
+            for key, col, dt in (("sp_cnt", COL_SP_CNT, torch.int32), ("roi_cnt", COL_ROI_CNT, torch.int32), ("chr_cnt", COL_CHR_CNT, torch.int32),
+                                 ("known_cnt", COL_KNOWN_CNT, torch.int32), ("junc_keys", COL_JUNC_KEYS, torch.int64), ("junc_counts", COL_JUNC_COUNTS, torch.int32)):
+                n = eng.export_size(col)
+                t = torch.empty(n, dtype=dt, device=dev)
+                if n:
+                    eng.export_device(col | COL_NO_SYNC, t.data_ptr())
+                tabs[key] = t
+            eng.export_device(COL_IR_NONDIR_F64 | COL_NO_SYNC, out["ir_f64"].data_ptr())
+            eng.export_device(COL_IR_NONDIR_U32 | COL_NO_SYNC, out["ir_u32"].data_ptr())
+            tabs["ir_f64"], tabs["ir_u32"] = out["ir_f64"], out["ir_u32"]
+            if eng.export_size(COL_IR_DIR_F64):
+                eng.export_device(COL_IR_DIR_F64 | COL_NO_SYNC, out["ir_dir_f64"].data_ptr())
+                eng.export_device(COL_IR_DIR_U32 | COL_NO_SYNC, out["ir_dir_u32"].data_ptr())
+                tabs["ir_dir_f64"], tabs["ir_dir_u32"] = out["ir_dir_f64"], out["ir_dir_u32"]
+            eng.sync()
+            out["got"] = irfdist.gather_tables(tabs, None)
+            t_d = time.perf_counter()
+        else:
+            tabs = {
+                "ir_f64": export(COL_IR_NONDIR_F64, (8, n_in), torch.float64),
+                "ir_u32": export(COL_IR_NONDIR_U32, (6, n_in), torch.int32),
+                "sp_cnt": export(COL_SP_CNT, None, torch.int32),
+                "roi_cnt": export(COL_ROI_CNT, None, torch.int32),
+                "chr_cnt": export(COL_CHR_CNT, None, torch.int32),
+                "known_cnt": export(COL_KNOWN_CNT, None, torch.int32),
+                "junc_keys": export(COL_JUNC_KEYS, None, torch.int64),
+                "junc_counts": export(COL_JUNC_COUNTS, None, torch.int32),
+            }
+            if eng.export_size(COL_IR_DIR_F64):
+                tabs["ir_dir_f64"] = export(COL_IR_DIR_F64, (8, n_in), torch.float64)
+                tabs["ir_dir_u32"] = export(COL_IR_DIR_U32, (6, n_in), torch.int32)
+            if coll_dev.type == "cpu":
+                tabs = {k: t.cpu() for k, t in tabs.items()}
+            got = irfdist.gather_tables(tabs, dist)
             torch.cuda.synchronize()
-            out["got"] = got
+            t_d = time.perf_counter()
+            if rank == 0:       # the IR table lands in page-locked host memory
+                if "ir_f64" not in out:
+                    out["ir_f64"] = torch.empty((8, n_in), dtype=torch.float64, pin_memory=True)
+                    out["ir_u32"] = torch.empty((6, n_in), dtype=torch.int32, pin_memory=True)
+                out["ir_f64"].copy_(got["ir_f64"], non_blocking=True)
+                out["ir_u32"].copy_(got["ir_u32"], non_blocking=True)
+                torch.cuda.synchronize()
+                out["got"] = got
         t_e = time.perf_counter()
         phase["reset+submit"] += t_b - t_a; phase["finalize"] += t_c - t_b
         phase["export+gather"] += t_d - t_c; phase["d2h"] += t_e - t_d
@@ -247,6 +271,8 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if world == 1:      # the timed steps wrote the IR tables into the page-locked buffers the later legs reuse: keep a copy
+        out["got"] = {k: (v.clone() if torch.is_tensor(v) and not v.is_cuda else v) for k, v in out["got"].items()}
     out["n_junc"] = sum(int(k.numel()) for k in out["got"]["junc_keys"])
     out["known_reads"] = int(out["got"]["known_cnt"].to(torch.int64).sum().item())
 

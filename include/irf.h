@@ -262,6 +262,10 @@ int irf_export_device(irf_ctx* ctx, uint32_t what, void* dst_device, uint64_t* n
  * irf_import_device).  Introns on no BAM reference at all belong to no shard: OR this flag into `what` on ONE rank
  * (the root) to keep its rows for them (all-zero depth, LowCover — what a single-GPU run reports).                  */
 #define IRF_COL_KEEP_ORPHANS 0x100u
+/* `dst_device` of irf_export_device may also be PAGE-LOCKED HOST memory (irf_host_alloc): the column then crosses PCIe
+ * once, without a device-side copy (not for the IR tables of a sharded context).  With IRF_COL_NO_SYNC OR-ed into `what`
+ * the copy is only queued on the context's stream: call irf_sync before reading `dst` (several columns, one wait).  */
+#define IRF_COL_NO_SYNC 0x200u
 
 /* ------------------------------------------------------------------------ */
 /* Multi-GPU collection for C / C++ hosts (SURVEY.md §8 e; no upstream counterpart: upstream is one process).

@@ -49,6 +49,7 @@ struct DevBuf {
     size_t cap = 0;      // elements
     ~DevBuf() { release(); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
     // grows (never shrinks); contents are NOT preserved
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
@@ -94,6 +95,13 @@ struct irf_ctx {
     // ---- device state ----
     DevBuf<int32_t> d_diff;
     DevBuf<uint32_t> d_seg_sum;                  // [2][plane_stride/256] sum of each segment of d_diff (count kernel)
+    // A second set of planes for the NEXT sample: cleared on a side stream once this sample's statistics kernels are done
+    // (while the host fetches the tables the GPU has nothing else to do), so irf_reset swaps instead of clearing in line.
+    DevBuf<int32_t> d_diff_alt;
+    DevBuf<uint32_t> d_seg_sum_alt;
+    hipStream_t clear_stream = nullptr;
+    hipEvent_t ev_stats_done = nullptr, ev_cleared = nullptr;
+    bool alt_clean = false;                      // d_*_alt are (being) cleared: ev_cleared says when
     DevBuf<uint32_t> d_carry;                    // [2][plane_stride/256] depth before each segment (after finalize)
     DevBuf<uint64_t> d_chr_base;
     DevBuf<uint32_t> d_chr_len;
@@ -235,6 +243,9 @@ int irf_ctx::init() {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&clear_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev_stats_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_cleared, hipEventDisableTiming));
     for (auto& s : stage) {
         HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
@@ -253,6 +264,9 @@ void irf_ctx::free_events() {
     for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto& p : count_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     count_events.clear();
+    if (ev_stats_done) { (void)hipEventDestroy(ev_stats_done); ev_stats_done = nullptr; }
+    if (ev_cleared) { (void)hipEventDestroy(ev_cleared); ev_cleared = nullptr; }
+    if (clear_stream) { (void)hipStreamDestroy(clear_stream); clear_stream = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
 }
@@ -335,6 +349,9 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     TRY(upload(this, d_chr_len, chr_len));
     TRY(upload(this, d_chr_owned, chr_owned));
     {
+        if (clear_stream) HIP_TRY(hipStreamSynchronize(clear_stream));
+        d_diff_alt.release(); d_seg_sum_alt.release();      // (a new map: the spare planes are allocated again when first needed)
+        alt_clean = false;
         hipError_t e = d_diff.reserve(2 * plane_stride);
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth planes failed");
     }
@@ -633,8 +650,16 @@ int irf_ctx::zero_counters() {
     // (clearing a second set of planes on a side stream was tried twice: under the next sample's count kernel that kernel
     //  slows down by exactly the time of the memset, under the statistics kernels they slow down by MORE than that
     //  (1.85 -> 3.13 ms) — both are latency-bound and lose to a bandwidth-bound neighbour; the planes are cleared in line)
-    if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
-    if (plane_stride) HIP_TRY(hipMemsetAsync(d_seg_sum.p, 0, 2 * plane_stride / dev::kDepthSegment * sizeof(uint32_t), stream));
+    if (alt_clean && d_diff_alt.cap >= 2 * plane_stride && d_seg_sum_alt.cap >= 2 * plane_stride / dev::kDepthSegment) {
+        // the spare planes were cleared behind the last sample's statistics: take them
+        d_diff.swap(d_diff_alt);
+        d_seg_sum.swap(d_seg_sum_alt);
+        HIP_TRY(hipStreamWaitEvent(stream, ev_cleared, 0));
+        alt_clean = false;
+    } else {
+        if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
+        if (plane_stride) HIP_TRY(hipMemsetAsync(d_seg_sum.p, 0, 2 * plane_stride / dev::kDepthSegment * sizeof(uint32_t), stream));
+    }
     if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
     if (n_roi) HIP_TRY(hipMemsetAsync(d_roi_cnt.p, 0, (size_t)n_roi * 2 * sizeof(uint32_t), stream));
     if (n_sp) HIP_TRY(hipMemsetAsync(d_sp_cnt.p, 0, (size_t)n_sp * 2 * sizeof(uint32_t), stream));
@@ -910,6 +935,22 @@ int irf_ctx::finalize() {
     else launch_stats(0, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], stream));
+    if (plane_stride && !alt_clean) {
+        // the next sample's planes: cleared on the side stream as soon as the statistics kernels have finished (a memset
+        // UNDER them costs them more than its own time; behind them the device is idle while the host fetches the tables)
+        const size_t n_seg2 = 2 * plane_stride / dev::kDepthSegment;
+        if (d_diff_alt.reserve(2 * plane_stride) == hipSuccess && d_seg_sum_alt.reserve(n_seg2) == hipSuccess) {
+            HIP_TRY(hipEventRecord(ev_stats_done, stream));
+            HIP_TRY(hipStreamWaitEvent(clear_stream, ev_stats_done, 0));
+            HIP_TRY(hipMemsetAsync(d_diff_alt.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
+            HIP_TRY(hipMemsetAsync(d_seg_sum_alt.p, 0, n_seg2 * sizeof(uint32_t), clear_stream));
+            HIP_TRY(hipEventRecord(ev_cleared, clear_stream));
+            alt_clean = true;
+        } else {
+            (void)hipGetLastError();           // no room for a second set: the planes are cleared in line, as before
+            d_diff_alt.release(); d_seg_sum_alt.release();
+        }
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     // ---- timing ----
     float ms = 0;
@@ -1044,8 +1085,8 @@ int irf_ctx::fetch_results() {
 int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
     if (!n_out) return IRF_E_ARG;
     if (!finalized) return fail(IRF_E_STATE, "irf_export_device before irf_finalize");
-    const bool keep_orphans = (what_in & IRF_COL_KEEP_ORPHANS) != 0;
-    const uint32_t what = what_in & ~(uint32_t)IRF_COL_KEEP_ORPHANS;
+    const bool keep_orphans = (what_in & IRF_COL_KEEP_ORPHANS) != 0, no_sync = (what_in & IRF_COL_NO_SYNC) != 0;
+    const uint32_t what = what_in & ~(uint32_t)(IRF_COL_KEEP_ORPHANS | IRF_COL_NO_SYNC);
     const void* src = nullptr;
     uint64_t n = 0;
     size_t elem = 4;
@@ -1066,14 +1107,21 @@ int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
     *n_out = n;
     if (!dst || !n) return 0;
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMemcpyAsync(dst, src, n * elem, hipMemcpyDeviceToDevice, stream));
+    if (table >= 0 && sharded) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) != hipSuccess || at.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            return fail(IRF_E_ARG, "irf_export_device: the IR tables of a sharded context are exported into DEVICE memory (their foreign rows are zeroed there)");
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, n * elem, hipMemcpyDefault, stream));       // dst: device memory, or page-locked host memory
     if (table >= 0 && sharded) {
         const uint32_t keep = (1u << dev::kRowMine) | (keep_orphans ? (1u << dev::kRowOrphan) : 0u);
         if (elem == 8) dev::launch_mask_rows_f64((double*)dst, 8, n_intron, d_row_code.p, keep, stream);
         else dev::launch_mask_rows_u32((uint32_t*)dst, 6, n_intron, d_row_code.p, keep, stream);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (!no_sync) HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -1232,6 +1280,7 @@ void irf_destroy(irf_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->clear_stream) (void)hipStreamSynchronize(c->clear_stream);
     c->free_events();
     delete c;
 }
