@@ -374,13 +374,34 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs A) {
     __shared__ unsigned long long s_stats[RS_COUNT];
     if (!WRITE && threadIdx.x < RS_COUNT) s_stats[threadIdx.x] = 0;
     const uint32_t i0 = blockIdx.x * kPairTile + threadIdx.x * kPerThread;
-    uint32_t last = last_unpaired_before(A, i0, s_w);     // (barrier inside: s_stats is zeroed for everyone)
+    uint32_t last = 0;
+    if (A.mate) __syncthreads();
+    else last = last_unpaired_before(A, i0, s_w);         // (barrier inside: s_stats is zeroed for everyone)
     uint32_t st[RS_COUNT];
 #pragma unroll
     for (int k = 0; k < RS_COUNT; k++) st[k] = 0;
     for (uint32_t k = 0; k < kPerThread; k++) {
         const uint32_t i = i0 + k;
         if (i >= A.n_rec) break;
+        if (A.mate) {
+            // name-joined pairing: the join kernels decided who completes what (records and nucleotides were counted
+            // when the records arrived)
+            const uint32_t m = A.mate[i];
+            Unit u{0, 0};
+            if (m < A.n_rec || m == JOIN_SINGLE) {
+                Out o{0, 0};
+                if (WRITE) { o.f = A.fr_cnt[i]; o.b = A.bl_cnt[i]; }
+                const Rec y = load_rec(A.buf, A.R.rec_off[i]);
+                if (m < A.n_rec) {
+                    const Rec x = load_rec(A.buf, A.R.rec_off[m]);
+                    if (!x.overrun && !y.overrun) u = process_unit<WRITE>(A, true, x, y, o, st);
+                } else if (!y.overrun) {
+                    u = process_unit<WRITE>(A, false, y, y, o, st);
+                }
+            }
+            if (!WRITE) { A.fr_cnt[i] = u.n_frag; A.bl_cnt[i] = u.n_blk; }
+            continue;
+        }
         const uint32_t nf = A.R.rec_nf[i];
         const bool paired = (nf >> 16) & 1u;
         const bool waiting = ((i - last) & 1u) != 0;      // an odd run of paired records precedes: record i is the mate
@@ -432,6 +453,98 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs A) {
     }
 }
 
+// ---- name-joined pairing -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long name_hash(const uint8_t* name, uint32_t n) {
+    unsigned long long h = 0x9E3779B97F4A7C15ull ^ n;
+    for (uint32_t k = 0; k < n; k++) {
+        h = (h ^ name[k]) * 0x100000001B3ull;
+        h ^= h >> 29;
+    }
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h == kJoinNoKey ? h - 1ull : h;
+}
+
+__global__ __launch_bounds__(kThreads) void join_keys_kernel(JoinArgs J) {
+    __shared__ unsigned long long s_stats[2];
+    if (threadIdx.x < 2) s_stats[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    unsigned long long nrec = 0, nnuc = 0;
+    if (i < J.n_rec) {
+        const uint64_t off = J.R.rec_off[i];
+        const Rec r = load_rec(J.buf, off);
+        if (r.overrun) atomicMin(J.R.err, (unsigned long long)(off << 2 | 2ull));
+        if (i >= J.n_old) { nrec = 1; if (r.l_seq > 0) nnuc = (unsigned long long)r.l_seq; }
+        const uint32_t l_name = J.buf[off + 12];
+        const bool paired = (r.flag & 1u) != 0 && !r.overrun;
+        J.keys[i] = paired ? name_hash(J.buf + off + 36, l_name ? l_name - 1u : 0u) : kJoinNoKey;
+        J.vals[i] = i;
+        J.mate[i] = JOIN_SINGLE;       // paired records are overwritten by their group's walk
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { nrec += __shfl_xor(nrec, d); nnuc += __shfl_xor(nnuc, d); }
+    if ((threadIdx.x & 63) == 0) { if (nrec) atomicAdd(&s_stats[0], nrec); if (nnuc) atomicAdd(&s_stats[1], nnuc); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_stats[0]) atomicAdd(&J.stats[RS_RECORDS], s_stats[0]);
+        if (s_stats[1]) atomicAdd(&J.stats[RS_NUCLEOTIDES], s_stats[1]);
+    }
+}
+
+__device__ __forceinline__ bool same_name(const uint8_t* buf, uint64_t a, uint64_t b) {
+    const uint32_t la = buf[a + 12], lb = buf[b + 12];
+    if (la != lb) return false;
+    for (uint32_t k = 0; k + 1 < la; k++)
+        if (buf[a + 36 + k] != buf[b + 36 + k]) return false;
+    return true;
+}
+
+// one thread per sorted position; the head of a group of equal hashes walks the group (arrival order: the sort is stable)
+__global__ __launch_bounds__(kThreads) void join_groups_kernel(JoinArgs J) {
+    const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
+    if (p >= J.n_rec) return;
+    const unsigned long long key = J.keys[p];
+    if (key == kJoinNoKey || (p > 0 && J.keys[p - 1] == key)) return;
+    uint32_t waiting = 0xffffffffu, displaced = 0;
+    for (uint32_t q = p; q < J.n_rec && J.keys[q] == key; q++) {
+        const uint32_t r = J.vals[q];
+        if (waiting == 0xffffffffu) { waiting = r; continue; }
+        if (!same_name(J.buf, J.R.rec_off[waiting], J.R.rec_off[r])) { *J.collision = 1u; continue; }
+        const uint32_t fw = J.R.rec_nf[waiting] >> 16, fr = J.R.rec_nf[r] >> 16;
+        if (((fw ^ fr) & 0xc0u) == 0u) {          // the same mate again: the waiting record is displaced
+            J.mate[waiting] = JOIN_DEAD;
+            displaced++;
+            waiting = r;
+        } else {
+            J.mate[waiting] = JOIN_FIRST;
+            J.mate[r] = waiting;
+            waiting = 0xffffffffu;
+        }
+    }
+    if (waiting != 0xffffffffu) J.mate[waiting] = JOIN_WAITING;
+    if (displaced) atomicAdd(&J.stats[RS_ERROR], (unsigned long long)displaced);
+}
+
+__global__ __launch_bounds__(kThreads) void join_sizes_kernel(JoinArgs J) {
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    uint32_t sz = 0;
+    if (i < J.n_rec && J.mate[i] == JOIN_WAITING) sz = 4u + ld32u(J.buf + J.R.rec_off[i]);
+    if (i <= J.n_rec) J.sizes[i] = sz;
+    const uint64_t w = __ballot(sz != 0u);
+    if (w && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)w) - 1)) atomicAdd(J.n_waiting, (uint32_t)__popcll(w));
+}
+
+// one wave per record: the waiting records, whole, in arrival order
+__global__ __launch_bounds__(kThreads) void join_carry_kernel(JoinArgs J, const uint32_t* __restrict__ offsets, uint8_t* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= J.n_rec || J.mate[i] != JOIN_WAITING) return;
+    const uint64_t src = J.R.rec_off[i];
+    const uint32_t n = 4u + ld32u(J.buf + src);
+    uint8_t* d = dst + offsets[i];
+    for (uint32_t k = lane; k < n; k += 64u) d[k] = J.buf[src + k];
+}
+
 __global__ void close_offsets_kernel(uint32_t* frag_blk_off, uint32_t n_frag, uint32_t n_blk) { frag_blk_off[n_frag] = n_blk; }
 
 }   // namespace
@@ -449,6 +562,19 @@ void launch_chain_verify(const ChainBufs& C, hipStream_t s) {
 void launch_chain_emit(const ChainBufs& C, const uint32_t* seg_base, const RecordIndex& R, hipStream_t s) {
     if (!C.n_seg) return;
     hipLaunchKernelGGL(chain_emit_kernel, dim3((C.n_seg + kThreads - 1) / kThreads), dim3(kThreads), 0, s, C, seg_base, R);
+}
+
+void launch_join_keys(const JoinArgs& J, hipStream_t s) {
+    if (J.n_rec) hipLaunchKernelGGL(join_keys_kernel, dim3((J.n_rec + kThreads - 1) / kThreads), dim3(kThreads), 0, s, J);
+}
+void launch_join_groups(const JoinArgs& J, hipStream_t s) {
+    if (J.n_rec) hipLaunchKernelGGL(join_groups_kernel, dim3((J.n_rec + kThreads - 1) / kThreads), dim3(kThreads), 0, s, J);
+}
+void launch_join_sizes(const JoinArgs& J, hipStream_t s) {
+    hipLaunchKernelGGL(join_sizes_kernel, dim3((J.n_rec + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, J);
+}
+void launch_join_carry(const JoinArgs& J, const uint32_t* offsets, uint8_t* dst, hipStream_t s) {
+    if (J.n_rec) hipLaunchKernelGGL(join_carry_kernel, dim3((J.n_rec + kThreads / 64 - 1) / (kThreads / 64)), dim3(kThreads), 0, s, J, offsets, dst);
 }
 
 uint32_t pair_tiles(uint32_t n_rec) { return (n_rec + kPairTile - 1) / kPairTile; }

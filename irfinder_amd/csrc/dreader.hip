@@ -170,6 +170,11 @@ struct irf_dreader {
     bool carry_dangling = false;             // the carry starts with a complete first mate that waits for its mate
     bool carry_partial = false;              // ... and / or ends with an incomplete record
     DBuf<uint32_t> d_count, d_seg_base, d_rec_nf, d_tile_last, d_tile_carry, d_fr, d_bl, d_ws;
+    // params.mate_join: name-joined pairing (bamparse.hip: join_*).  The records still waiting for their mate travel in
+    // the carry, in front of the partial record (if any): they are the first n_old records of the next feed.
+    DBuf<unsigned long long> d_jkeys[2];
+    DBuf<uint32_t> d_jvals[2], d_mate, d_jsizes, d_joffs, d_ws_sort;
+    uint32_t n_old = 0;
     DBuf<uint64_t> d_guess, d_exit, d_rec_off;
     DBuf<unsigned long long> d_scal;         // [0] record error, [1 .. 1 + RS_COUNT) reader statistics
     DBuf<uint32_t> d_flags;                  // [0] dangling, [8 .. 8 + kVerifyBatch) chain changed, one word per verify launch of a batch
@@ -456,6 +461,9 @@ int irf_dreader::stage2(InSlot& S) {
     HIP_TRY(hipMemsetAsync(f_dangling, 0, 4, stream));
     dev::AssembleArgs A;
     memset(&A, 0, sizeof A);
+    dev::JoinArgs J;
+    memset(&J, 0, sizeof J);
+    uint32_t collision = 0;
     if (n_rec) {
         g_trace.mark("stage2: reserving record index");
         MEM_TRY(d_rec_off.reserve(n_rec));
@@ -468,7 +476,28 @@ int irf_dreader::stage2(InSlot& S) {
         g_trace.mark("stage2: record index reserved");
         dev::RecordIndex R{d_rec_off.p, d_rec_nf.p, d_scal.p};
         dev::launch_chain_emit(C, d_seg_base.p, R, stream);
-        dev::launch_pair_state(d_rec_nf.p, n_rec, d_tile_last.p, d_tile_carry.p, stream);
+        if (P.mate_join) {
+            // pairs by read name: hash, stable sort of (hash, record index), one walk per group of equal hashes
+            MEM_TRY(d_jkeys[0].reserve(n_rec)); MEM_TRY(d_jkeys[1].reserve(n_rec));
+            MEM_TRY(d_jvals[0].reserve(n_rec)); MEM_TRY(d_jvals[1].reserve(n_rec));
+            MEM_TRY(d_mate.reserve(n_rec)); MEM_TRY(d_jsizes.reserve((size_t)n_rec + 4)); MEM_TRY(d_joffs.reserve((size_t)n_rec + 4));
+            MEM_TRY(d_ws_sort.reserve(std::max(dev::radix_workspace_elems(n_rec), dev::scan_workspace_elems((uint64_t)n_rec + 1))));
+            J.buf = raw; J.n_rec = n_rec; J.n_old = std::min(n_old, n_rec); J.R = R;
+            J.keys = d_jkeys[0].p; J.vals = d_jvals[0].p; J.mate = d_mate.p; J.stats = d_scal.p + 1; J.collision = f_dangling + 1; J.n_waiting = f_dangling + 2; J.sizes = d_jsizes.p;
+            HIP_TRY(hipMemsetAsync(f_dangling + 1, 0, 8, stream));
+            dev::launch_join_keys(J, stream);
+            int from = 0;
+            for (int shift = 0; shift < 64; shift += 8) {
+                dev::launch_radix_pass((const uint64_t*)d_jkeys[from].p, (uint64_t*)d_jkeys[from ^ 1].p, d_jvals[from].p, d_jvals[from ^ 1].p, n_rec, shift,
+                                       d_ws_sort.p, stream);
+                from ^= 1;
+            }
+            J.keys = d_jkeys[from].p; J.vals = d_jvals[from].p;
+            dev::launch_join_groups(J, stream);
+            A.mate = d_mate.p;
+        } else {
+            dev::launch_pair_state(d_rec_nf.p, n_rec, d_tile_last.p, d_tile_carry.p, stream);
+        }
         A.buf = raw; A.n_rec = n_rec; A.n_ref = n_ref; A.R = R; A.tile_carry = d_tile_carry.p;
         A.skip_flag_mask = P.skip_flag_mask; A.pair_long_inclusive = P.pair_long_inclusive; A.pair_short_inclusive = P.pair_short_inclusive; A.gap_pair_is_intersect = P.gap_pair_is_intersect;
         A.fr_cnt = d_fr.p; A.bl_cnt = d_bl.p; A.stats = d_scal.p + 1; A.dangling = f_dangling;
@@ -480,6 +509,7 @@ int irf_dreader::stage2(InSlot& S) {
         HIP_TRY(hipMemcpyAsync(&n_frag, d_fr.p + n_rec, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&n_blk, d_bl.p + n_rec, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(&dangling, f_dangling, 4, hipMemcpyDeviceToHost, stream));
+        if (P.mate_join) HIP_TRY(hipMemcpyAsync(&collision, f_dangling + 1, 4, hipMemcpyDeviceToHost, stream));
     } else if (n_seg) {
         // no complete record: a broken chain in the first segment still has to be reported
         dev::RecordIndex R{nullptr, nullptr, d_scal.p};
@@ -491,6 +521,7 @@ int irf_dreader::stage2(InSlot& S) {
     g_trace.mark("stage2: counted");
     if (scal[0] != ~0ull) return fail(IRF_E_PARSE, (scal[0] & 3ull) == 1ull ? "BAM: bad block_size" : "BAM: record fields overrun block_size");
     if (tail_off == dev::kNoRecord) return fail(IRF_E_DEVICE, "record chain broken without a bad record (internal error)");
+    if (collision) return fail(IRF_E_RANGE, "two different read names share a 64-bit hash: read this file with the host reader (irf_reader_*)");
 
     MEM_TRY(O.frag_chr.reserve(n_frag + 4)); MEM_TRY(O.frag_flags.reserve(n_frag + 4)); MEM_TRY(O.frag_start.reserve(n_frag + 4));
     MEM_TRY(O.frag_end.reserve(n_frag + 4)); MEM_TRY(O.frag_blk_off.reserve((size_t)n_frag + 5));
@@ -503,6 +534,34 @@ int irf_dreader::stage2(InSlot& S) {
     O.n_frag = n_frag; O.n_blk = n_blk;
 
     // ---- carry: everything behind the last complete unit ----
+    if (P.mate_join) {
+        // the records that still wait for their mate (whole, in arrival order), then the incomplete record at the end
+        uint32_t wait[2] = {0, 0};           // bytes, records
+        if (n_rec) {
+            dev::launch_join_sizes(J, stream);
+            dev::launch_exclusive_scan_u32(d_jsizes.p, d_joffs.p, (uint64_t)n_rec + 1, d_ws_sort.p, stream);
+            HIP_TRY(hipMemcpyAsync(&wait[0], d_joffs.p + n_rec, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&wait[1], f_dangling + 2, 4, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        g_trace.mark("stage2: written");
+        const uint64_t tail_bytes = total - tail_off;
+        const uint64_t new_carry = (uint64_t)wait[0] + tail_bytes;
+        if (new_carry) {
+            // (the carry buffer is a second copy: the next feed's stage 1 may already be writing the other slot's `raw`)
+            MEM_TRY(d_carry.reserve(std::max<uint64_t>(new_carry + 64, kMinGap)));
+            if (wait[0]) {
+                dev::launch_join_carry(J, d_joffs.p, d_carry.p, stream);
+                HIP_TRY(hipGetLastError());
+            }
+            if (tail_bytes) HIP_TRY(hipMemcpyAsync(d_carry.p + wait[0], raw + tail_off, tail_bytes, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        carry_len = new_carry;
+        carry_dangling = false;
+        carry_partial = tail_bytes != 0;
+        n_old = wait[1];           // the next feed walks them again, as its first records
+    } else {
     uint64_t tail_from = tail_off;
     if (dangling) HIP_TRY(hipMemcpyAsync(&tail_from, d_rec_off.p + (n_rec - 1), 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -517,6 +576,7 @@ int irf_dreader::stage2(InSlot& S) {
     carry_len = new_carry;
     carry_dangling = dangling != 0;
     carry_partial = tail_off != total;
+    }
     g_trace.mark("stage2: done");
 
     stats.n_records += scal[1 + dev::RS_RECORDS]; stats.n_nucleotides += scal[1 + dev::RS_NUCLEOTIDES];
@@ -551,6 +611,12 @@ int irf_dreader::finish() {
     if (!pending.empty()) return fail(IRF_E_PARSE, "BGZF: truncated block at end of input");
     if (!header_done) return fail(IRF_E_PARSE, "BAM: truncated header");
     if (carry_partial) return fail(IRF_E_PARSE, "BAM: truncated record at end of input");
+    if (P.mate_join && n_old) {
+        // records whose mate never arrived: error reads (host reader: every record still waiting at the end of input)
+        stats.n_error += n_old;
+        n_old = 0;
+        carry_len = 0;
+    }
     if (carry_dangling) {
         // the first mate is a record like any other: count it, and the read as an error (as the host reader does)
         int32_t l_seq = 0;
@@ -597,7 +663,7 @@ int irf_dreader_create(const irf_params* params, int device, irf_dreader** out) 
     } else {
         irf_params_default(&P);
     }
-    if (P.mate_join) return IRF_E_ARG;      // name join of coordinate-sorted input: host reader only (for now)
+
     irf_dreader* r = new (std::nothrow) irf_dreader();
     if (!r) return IRF_E_NOMEM;
     r->P = P;

@@ -82,10 +82,45 @@ struct AssembleArgs {
     uint32_t* bl_cnt;             // [n_rec+1] aligned blocks of that fragment; after the scan: their offset
     unsigned long long* stats;    // [RS_COUNT]
     uint32_t* dangling;           // [1] 1: the last record opens a pair whose mate is not in this buffer (not consumed)
+    const uint32_t* mate;         // name-joined pairing (params.mate_join): per record a JoinCode or the index of its first mate;
+                                  // nullptr: upstream's pairing (the next record is the mate)
     // outputs of the write pass (irf_batch columns)
     uint32_t* frag_chr; uint8_t* frag_flags; uint32_t* frag_start; uint32_t* frag_end; uint32_t* frag_blk_off;
     uint32_t* blk_start; uint32_t* blk_len; uint8_t* blk_read;
 };
+// ---- name-joined pairing (params.mate_join = 1: coordinate-sorted input) -------------------------
+// host/bam_reader.cpp: on_paired_by_name, on the device.  A paired record waits under its read name until the record
+// of the OTHER mate (flag 0x40 / 0x80) arrives; a second record of the SAME mate displaces the waiting one (an error
+// read).  Per feed: a 64-bit hash of every paired record's name, a stable radix sort of (hash, record index), then one
+// thread per group of equal hashes walks its records in arrival order (names compared byte for byte: two names with
+// one hash are reported, not mis-paired).  Records still waiting at the end of a feed are copied, whole, in front of
+// the next feed's inflated bytes and take part again as its first n_old records.
+enum JoinCode : uint32_t {
+    JOIN_SINGLE = 0xfffffff0u,    // not a paired record: a fragment of its own
+    JOIN_FIRST = 0xfffffff1u,     // first mate of a pair completed by a later record (no output of its own)
+    JOIN_WAITING = 0xfffffff2u,   // its mate has not arrived: carried to the next feed
+    JOIN_DEAD = 0xfffffff3u       // displaced by a second record of the same mate (counted as an error read)
+};
+constexpr unsigned long long kJoinNoKey = ~0ull;
+struct JoinArgs {
+    const uint8_t* buf;
+    uint32_t n_rec, n_old;        // records [0, n_old) were carried over: counted when they first arrived
+    RecordIndex R;
+    unsigned long long* keys;     // [n_rec] name hash (kJoinNoKey: not paired)
+    uint32_t* vals;               // [n_rec] record index
+    uint32_t* mate;               // [n_rec] JoinCode / first-mate index
+    unsigned long long* stats;    // [RS_COUNT]
+    uint32_t* collision;          // [1] set when two different names share a hash
+    uint32_t* n_waiting;          // [1] records still waiting for their mate (join_sizes adds them up)
+    uint32_t* sizes;              // [n_rec + 1] bytes of the record if it is carried, else 0 (then scanned)
+};
+void launch_join_keys(const JoinArgs& J, hipStream_t s);
+// keys / vals sorted by key (stable): fills mate[]
+void launch_join_groups(const JoinArgs& J, hipStream_t s);
+void launch_join_sizes(const JoinArgs& J, hipStream_t s);
+// offsets = exclusive scan of sizes: copies the waiting records, in arrival order, to dst
+void launch_join_carry(const JoinArgs& J, const uint32_t* offsets, uint8_t* dst, hipStream_t s);
+
 uint32_t pair_tiles(uint32_t n_rec);
 // (index of the last record without the paired flag in each tile) + 1, then the exclusive running maximum over tiles
 void launch_pair_state(const uint32_t* rec_nf, uint32_t n_rec, uint32_t* tile_last, uint32_t* tile_carry, hipStream_t s);

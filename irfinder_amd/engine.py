@@ -305,7 +305,7 @@ class DeviceReader:
         self.h = C.c_void_p()
         rc = self.L.irf_dreader_create(C.byref(self.params), int(device), C.byref(self.h))
         if rc != 0:
-            raise IrfError(rc, "irf_dreader_create failed (no HIP device, or params.mate_join set)")
+            raise IrfError(rc, "irf_dreader_create failed (no HIP device or bad parameters)")
         if pipeline:
             self._chk(self.L.irf_dreader_set_pipeline(self.h, 1))
 

@@ -52,7 +52,7 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
     irf_ref_free(ref);
     if (rc != 0) return die("irf_create", "no HIP device or bad parameters");
     irf_dreader* dr = nullptr;
-    if (irf_dreader_create(&P, device, &dr) != 0) return die("irf_dreader_create", "no HIP device, or --sorted (name join is host-only)");
+    if (irf_dreader_create(&P, device, &dr) != 0) return die("irf_dreader_create", "no HIP device or bad parameters");
     // pipelined: while a piece is copied and inflated, the fragments of the piece before it are assembled and counted,
     // and stdin is read for the next one
     if (irf_dreader_set_pipeline(dr, 1) != 0) return die("irf_dreader_set_pipeline", irf_dreader_last_error(dr));

@@ -181,8 +181,6 @@ def test_device_reader_edge_records_and_switches():
         ob, ost, _ = orc.bam_to_batch(bam, orc.default_params(**over))
         _, db, ds, _ = device_read(bgzf_compress(bam), **over)
         assert db.equals(ob) and ds == ost, over
-    with pytest.raises(engine.IrfError):
-        engine.DeviceReader(engine.default_params(mate_join=1))
 
 
 def test_device_reader_record_payload_that_looks_like_records():
@@ -254,6 +252,61 @@ def test_four_samples_streamed_through_one_context_with_overlapped_reading():
             o.finalize()
             assert_results_equal(got, o.results(), rel=0.0, what="sample %d" % k)
             assert got["n_fragments"] > 8000
+
+
+def _split_bam(bam):
+    l_text, = struct.unpack_from("<i", bam, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", bam, o)
+    o += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", bam, o)
+        o += 4 + l_name + 4
+    head, recs = bam[:o], []
+    while o < len(bam):
+        bs, = struct.unpack_from("<i", bam, o)
+        recs.append(bam[o:o + 4 + bs])
+        o += 4 + bs
+    return head, recs
+
+
+def test_device_reader_joins_mates_by_name_on_coordinate_sorted_input():
+    """params.mate_join = 1 on the device (north_star's input order): the coordinate-sorted file through
+    irf_dreader_* gives the host reader's batch — column by column, in the same order — and the same counters, for any
+    chunking and with the pipeline; irregular records included: an orphan, a pair split over two chromosomes (its mates
+    are feeds apart), an unmapped mate, a displaced first mate (a second record of the SAME mate under one name),
+    unpaired reads in between."""
+    ann, sim = small_world(seed=37, single_frac=0.05)
+    bam = sim.bam(0, 9000)
+    head, recs = _split_bam(bam)
+    extra = records_to_bam(ann.chr_names, ann.chr_lens, [
+        dict(ref_id=0, pos=5000, flag=0x41, cigar="50M", name="orphan"),
+        dict(ref_id=0, pos=6000, flag=0x41, cigar="50M", name="split"), dict(ref_id=2, pos=6000, flag=0x81, cigar="50M", name="split"),
+        dict(ref_id=0, pos=7000, flag=0x41, cigar="50M", name="half"), dict(ref_id=0, pos=7000, flag=0x81 | 0x4, cigar="50M", name="half"),
+        dict(ref_id=1, pos=100, flag=0x41, cigar="50M", name="twice"), dict(ref_id=1, pos=200, flag=0x41 | 0x100, cigar="40M", name="twice"),
+        dict(ref_id=1, pos=90000, flag=0x81, cigar="50M10N20M", name="twice"),
+        dict(ref_id=1, pos=300000, flag=0x41, cigar="30M", name="late-orphan")])
+    recs_x = _split_bam(extra)[1]
+
+    def key(rec):
+        ref_id, pos = struct.unpack_from("<ii", rec, 4)
+        return (ref_id if ref_id >= 0 else 1 << 30, pos)
+    srt = sorted(recs + recs_x, key=key)
+    data = head + b"".join(srt)
+    P = dict(mate_join=1)
+    r = engine.Reader(engine.default_params(**P))
+    r.feed(data)
+    r.finish()
+    want, want_stats = r.take_batch(), r.stats()
+    assert want_stats["n_error"] >= 5 and want_stats["n_pairs"] > 8000 and want_stats["n_singles"] > 100
+    z = bgzf_compress(data, block=0x3000)
+    for pieces, pipeline in ((None, False), ([len(z) // 7 + 1], False), ([70001, 333], False), ([len(z) // 5 + 1], True), ([9999], True)):
+        _, db, ds, d = device_read(z, pieces, pipeline, **P)
+        assert ds == want_stats, (pieces, pipeline, ds, want_stats)
+        assert db.equals(want), (pieces, pipeline)
+    # the same file read the upstream way (adjacent records are mates) is mis-paired: that is D-1
+    _, db0, ds0, _ = device_read(z)
+    assert not db0.equals(want)
 
 
 def test_device_reader_fault_injection():

@@ -343,7 +343,8 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam"),
                             ("sorted", ["--bgzf", "--sorted", "--threads", "4"], "sorted.bam"),
                             ("device-reader", ["--device-reader"], "in.bam"), ("device-reader-1mb", ["--device-reader", "--feed-mb", "1"], "in.bam"),
-                            ("device-reader-pipe", ["--device-reader"], "in.bam")):
+                            ("device-reader-pipe", ["--device-reader"], "in.bam"),
+                            ("device-reader-sorted", ["--device-reader", "--sorted", "--feed-mb", "1"], "sorted.bam")):
         out = tmp_path / tag
         out.mkdir()
         if tag.endswith("-pipe"):      # stdin is a pipe (read in pieces); the other device-reader runs map the file
