@@ -5,7 +5,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 280 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench > $out/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/$c.log; exit 1; }
+  timeout -s KILL 280 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench --no-random-leg > $out/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/$c.log; exit 1; }
 done
 python3 - $out <<'P'
 import csv, glob, json, sys, collections, re
@@ -16,7 +16,7 @@ for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True
         m = re.search(r'(\w+_kernel(?:<\d+)?|fillBufferAligned|copyBuffer)', name)
         key = m.group(1) if m else name[:40]
         vals[key][r['Counter_Name']].append(float(r['Counter_Value']))
-out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench (two separate passes)",
+out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench --no-random-leg (two separate passes)",
        "unit": "bytes per launch (mean over launches)",
        "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section; factor 2.0 calibrated in r01b on a kernel that read exactly 2*plane_positions*4 B)",
        "kernels": {}}
