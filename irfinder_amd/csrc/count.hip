@@ -512,26 +512,27 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                         if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
                         else atomicAdd(&sp_cnt[T.sp_row[pi]], 1u);
                     };
+                    // which of the four requested candidates lie inside [lo, hi] (the points are sorted: the first one beyond
+                    // hi ends the search); the counter updates then run ONCE per qualifying point, not once per candidate
                     bool done = false;
+                    uint32_t qual = 0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         if (p + q < p1 && !done) {
                             const uint32_t g = sp_g[j][q];
                             if ((int32_t)(g - hi) > 0) done = true;
-                            else if ((int32_t)(g - lo) >= 0) point(p + q);
+                            else if ((int32_t)(g - lo) >= 0) qual |= 1u << q;
                         }
                     }
-                    for (p += 4u; !done && p < p1; p += 4u) {
-                        uint32_t gp[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) gp[q] = T.sp_pos32[p + q < p1 ? p + q : p1 - 1u];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            if (p + q < p1 && !done) {
-                                if ((int32_t)(gp[q] - hi) > 0) done = true;
-                                else if ((int32_t)(gp[q] - lo) >= 0) point(p + q);
-                            }
-                        }
+                    while (qual) {
+                        const uint32_t q = (uint32_t)__ffs((int)qual) - 1u;
+                        qual &= qual - 1u;
+                        point(p + q);
+                    }
+                    for (p += 4u; !done && p < p1; p++) {          // a block over a dense stretch of points (rare)
+                        const uint32_t g = T.sp_pos32[p];
+                        if ((int32_t)(g - hi) > 0) done = true;
+                        else if ((int32_t)(g - lo) >= 0) point(p);
                     }
                 }
                 if (jc[j] && hit[j] == kEmpty) {
