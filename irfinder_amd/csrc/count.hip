@@ -106,8 +106,8 @@ struct Lds {
     uint32_t fb[kChunk];               // chr_base >> 6 | strand << 30 | counted << 31
     uint32_t fclen[kChunk];            // chromosome length
     int32_t tile[kWin];                // difference window: low half strand 0, high half strand 1
-    uint32_t ltag[kLines];             // far-event line cache: (plane position >> 4) * 2 + strand
-    int32_t lcnt[kLines][16];
+    uint32_t ltag[kLines];             // far-event line cache: plane position >> 4
+    int32_t lcnt[kLines][16];          // both strands of a position in one word, as in the window (low half strand 0)
     uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
     uint32_t jcnt[2][kJCache];
     uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_pos32
@@ -163,11 +163,13 @@ __device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsign
     seg_add(T, dir, c, v);
     return;
 #endif
-    const uint32_t want = (uint32_t)(c >> 4) * 2u + dir;
-    const uint32_t slot = ((uint32_t)(c >> 4) ^ (dir * (kLines / 2u))) & (kLines - 1u);
-    uint32_t tag = S.ltag[slot];
+    // (a line holds both strands, packed like the window: unstranded reads put both on the same positions, so this is
+    //  twice the lines for the same LDS; the packed halves cannot overflow while use_win holds)
+    const uint32_t want = (uint32_t)(c >> 4);
+    const uint32_t slot = want & (kLines - 1u);
+    uint32_t tag = use_win ? S.ltag[slot] : kEmpty - 1u;
     if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ltag[slot], kEmpty, want); tag = old == kEmpty ? want : old; }
-    if (tag == want) atomicAdd(&S.lcnt[slot][c & 15u], v);
+    if (tag == want) atomicAdd(&S.lcnt[slot][c & 15u], dir ? v * 65536 : v);
     else {
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_add(T, dir, c, v);
@@ -611,13 +613,17 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             const uint32_t slot = e >> 4, cell = e & 15u;               // a 16-lane row = one line = inside one segment
             const uint32_t tag = S.ltag[slot];
             const int32_t v = tag != kEmpty ? S.lcnt[slot][cell] : 0;
-            const uint64_t c = ((uint64_t)(tag >> 1) << 4) + cell;
+            const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
+            const int32_t v1 = (v - v0) >> 16;
+            const uint64_t c = ((uint64_t)tag << 4) + cell;
             if (v) {
-                if (!(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + (uint64_t)(tag & 1u) * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v0 && !(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + c, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v1 && !(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + T.plane_stride + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 S.lcnt[slot][cell] = 0;
             }
-            const int32_t line_sum = row_sum_dpp(v);
-            if (cell == 15u && line_sum) seg_add(T, tag & 1u, c, line_sum);
+            const int32_t s0 = row_sum_dpp(v0), s1 = row_sum_dpp(v1);
+            if (cell == 15u && s0) seg_add(T, 0u, c, s0);
+            if (cell == 15u && s1) seg_add(T, 1u, c, s1);
         }
         for (uint32_t e0 = 0; e0 <= wtop; e0 += kThreads) {
             const uint32_t e = e0 + tid;                                // < kWin: the window is a multiple of the workgroup
