@@ -105,7 +105,7 @@ struct Lds {
     uint32_t off[kChunk + 4];          // CSR offsets of the chunk's fragments (clamped to n_blk); [kChunk] = end
     uint32_t fb[kChunk];               // chr_base >> 6 | strand << 30 | counted << 31
     uint32_t fclen[kChunk];            // chromosome length
-    int32_t tile[kWin];                // difference window: low half strand 0, high half strand 1
+    int32_t tile[kWin + 64];           // difference window: low half strand 0, high half strand 1 (+ one idle cell per lane)
     uint32_t ltag[kLines];             // far-event line cache: plane position >> 4
     int32_t lcnt[kLines][16];          // both strands of a position in one word, as in the window (low half strand 0)
     uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
@@ -148,16 +148,8 @@ __device__ __forceinline__ uint64_t plane_of(const CountTables& T, uint32_t m, u
     return (m & 1u) ? c + (g & ((1u << kBucketShift) - 1u)) : c;
 }
 
-// One difference event at plane position c: the chunk's LDS window if it is inside, else the line cache, else
-// (line slot taken by another line) a global atomic.
-__device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsigned long long win, bool use_win, uint64_t c,
-                                            uint32_t dir, int v, uint32_t& wmax) {
-    const uint64_t o = c - win;
-    if (use_win && o < kWin) {
-        atomicAdd(&S.tile[o], dir ? v * 65536 : v);
-        wmax = (uint32_t)o > wmax ? (uint32_t)o : wmax;
-        return;
-    }
+// A difference event outside the chunk's window: the line cache, else (line slot taken by another line) a global atomic.
+__device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use_win, uint64_t c, uint32_t dir, int v) {
 #ifdef K_NOLINES
     __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seg_add(T, dir, c, v);
@@ -174,6 +166,21 @@ __device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, unsign
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_add(T, dir, c, v);
     }
+}
+
+// One difference event at plane position c, with a predicate instead of a branch around the call: the chunk's LDS window if
+// it is inside, else far_event.  The window update is executed by every lane (lanes
+// without an event, or with a far one, add 0 to a cell of their own behind the window), so that only the far path is a
+// branch — the kernel is bound by instruction issue, and the exec-mask bookkeeping of a branch costs as much as the update.
+__device__ __forceinline__ void depth_event_p(const CountTables& T, Lds& S, unsigned long long win, bool use_win, uint64_t c,
+                                              uint32_t dir, int v, bool pred, uint32_t& wmax) {
+    const uint64_t o = c - win;
+    const bool near = pred && use_win && o < kWin;
+    const uint32_t idx = near ? (uint32_t)o : kWin + (threadIdx.x & 63u);
+    atomicAdd(&S.tile[idx], near ? (dir ? v * 65536 : v) : 0);
+    const uint32_t om = near ? (uint32_t)o : 0u;
+    wmax = om > wmax ? om : wmax;
+    if (pred && !near) far_event(T, S, use_win, c, dir, v);
 }
 
 // n reads of strand dir on known junction idx: the chunk's LDS counter, or (slot taken by another junction) straight to
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
     __shared__ __align__(16) Lds S;
     const uint32_t tid = threadIdx.x;
     for (int k = tid; k < kChrBins; k += kThreads) S.chr[k] = 0;
-    for (int k = tid; k < (int)kWin; k += kThreads) S.tile[k] = 0;
+    for (int k = tid; k < (int)kWin + 64; k += kThreads) S.tile[k] = 0;
     for (int k = tid; k < (int)kLines; k += kThreads) S.ltag[k] = kEmpty;
     for (int k = tid; k < (int)kLines * 16; k += kThreads) S.lcnt[k >> 4][k & 15] = 0;
     for (int k = tid; k < (int)kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
@@ -485,19 +492,27 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             }
             CPROF(3);
             // difference events, SpansPoint, novel junctions
+            if (!(T.ablate & 1u)) {
+                // CoverageBlocks / FragmentsMap.  Every block end is one event site (unless a known junction's counter
+                // stands for it), every block start is one: of the lane's own first block only when it opens a fragment,
+                // of the others (the block after the lane's last included) when they open a fragment or follow a
+                // predecessor whose junction was not folded.  9 sites for 4 blocks, each with a predicate, not a branch.
+#pragma unroll
+                for (int j = 0; j < kVec; j++)
+                    depth_event_p(T, S, win, use_win, plane_of(T, ee[j].x, gbe[j]), (fbv[j] & kFragDir) ? 1u : 0u, -1, ok[j] && !folded[j], wmax);
+                depth_event_p(T, S, win, use_win, plane_of(T, es[0].x, gbs[0]), (fbv[0] & kFragDir) ? 1u : 0u, 1, ok[0] && first[0], wmax);
+#pragma unroll
+                for (int k = 1; k <= kVec; k++) {
+                    const bool opens = k < kVec && ok[k < kVec ? k : 0] && first[k < kVec ? k : 0];
+                    const bool follows = ok[k - 1] && !folded[k - 1] && next_same[k - 1] && ok[k];
+                    const uint32_t f = opens ? fbv[k < kVec ? k : 0] : fbv[k - 1];
+                    depth_event_p(T, S, win, use_win, plane_of(T, es[k].x, gbs[k]), (f & kFragDir) ? 1u : 0u, 1, opens || follows, wmax);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kVec; j++) {
                 if (!ok[j]) continue;
                 const uint32_t dir = (fbv[j] & kFragDir) ? 1u : 0u;
-                if (!(T.ablate & 1u)) {
-                    // CoverageBlocks / FragmentsMap.  A block emits its own end and its successor's start (unless a
-                    // known junction's counter stands for both); a fragment's first block also emits its own start.
-                    if (first[j]) depth_event(T, S, win, use_win, plane_of(T, es[j].x, gbs[j]), dir, 1, wmax);
-                    if (!folded[j]) {
-                        depth_event(T, S, win, use_win, plane_of(T, ee[j].x, gbe[j]), dir, -1, wmax);
-                        if (next_same[j] && ok[j + 1]) depth_event(T, S, win, use_win, plane_of(T, es[j + 1].x, gbs[j + 1]), dir, 1, wmax);
-                    }
-                }
                 // SpansPoint: the points of the buckets under the block, filtered to [lo, hi].  The first four were
                 // requested above (they usually are the block's own exon boundaries, just outside [lo, hi], and the
                 // few points inside); more only for a block over a dense stretch
