@@ -107,7 +107,7 @@ struct Lds {
     uint32_t fclen[kChunk];            // chromosome length
     int32_t tile[kWin + 64];           // difference window: low half strand 0, high half strand 1 (+ one idle cell per lane)
     uint32_t ltag[kLines];             // far-event line cache: plane position >> 4
-    int32_t lcnt[kLines][16];          // both strands of a position in one word, as in the window (low half strand 0)
+    int32_t lcnt[kLines + 1][16];      // both strands of a position in one word, as in the window (low half strand 0); line kLines: idle
     uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
     uint32_t jcnt[2][kJCache];
     uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_pos32
@@ -157,12 +157,14 @@ __device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use
 #endif
     // (a line holds both strands, packed like the window: unstranded reads put both on the same positions, so this is
     //  twice the lines for the same LDS; the packed halves cannot overflow while use_win holds)
+    // (one compare-and-swap claims an empty slot or returns the line that holds it: no read + branch in front of it; the
+    //  counter update is predicated like the window's — line kLines is nobody's — so only a conflict is a branch)
     const uint32_t want = (uint32_t)(c >> 4);
     const uint32_t slot = want & (kLines - 1u);
-    uint32_t tag = use_win ? S.ltag[slot] : kEmpty - 1u;
-    if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ltag[slot], kEmpty, want); tag = old == kEmpty ? want : old; }
-    if (tag == want) atomicAdd(&S.lcnt[slot][c & 15u], dir ? v * 65536 : v);
-    else {
+    const uint32_t old = atomicCAS(&S.ltag[slot], kEmpty, want);
+    const bool mine = use_win && (old == kEmpty || old == want);
+    atomicAdd(&S.lcnt[mine ? slot : kLines][c & 15u], mine ? (dir ? v * 65536 : v) : 0);
+    if (!mine) {
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_add(T, dir, c, v);
     }
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
     for (int k = tid; k < kChrBins; k += kThreads) S.chr[k] = 0;
     for (int k = tid; k < (int)kWin + 64; k += kThreads) S.tile[k] = 0;
     for (int k = tid; k < (int)kLines; k += kThreads) S.ltag[k] = kEmpty;
-    for (int k = tid; k < (int)kLines * 16; k += kThreads) S.lcnt[k >> 4][k & 15] = 0;
+    for (int k = tid; k < (int)(kLines + 1) * 16; k += kThreads) S.lcnt[k >> 4][k & 15] = 0;
     for (int k = tid; k < (int)kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
     for (int k = tid; k < (int)kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
     for (int k = tid; k < (int)kNovelH; k += kThreads) { S.nh_key[k] = kEmpty64; S.nh_cnt[k] = 0; }
