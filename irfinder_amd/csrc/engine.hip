@@ -76,6 +76,8 @@ struct irf_ctx {
     RefTables ref;
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t junc_stream = nullptr;           // the novel-junction sort of irf_finalize, next to the statistics kernels
+    hipEvent_t ev_junc_done = nullptr;
     std::string err;
     bool have_map = false, finalized = false, results_ready = false;
     bool kj_depth_applied = false;               // the known-junction difference events of this sample are in the planes (finalize may be called again after a failure)
@@ -190,6 +192,7 @@ struct irf_ctx {
     int submit(const irf_batch* b, uint64_t* id);
     int wait(uint64_t id);
     void launch_stats(int t, int dirn, bool dual = false);
+    dev::IntronTables intron_tables(int t, int dirn, bool dual);
     int finalize();
     int finalize_directional(int32_t dirn);
     int fetch_results();
@@ -244,6 +247,14 @@ int irf_ctx::init() {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&clear_stream, hipStreamNonBlocking));
+    {
+        // the sort's many small kernels run while the statistics kernels fill the device: highest priority, so that they
+        // get the next free slot
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&junc_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreate(&ev_junc_done));
+    }
     HIP_TRY(hipEventCreateWithFlags(&ev_stats_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_cleared, hipEventDisableTiming));
     for (auto& s : stage) {
@@ -269,6 +280,8 @@ void irf_ctx::free_events() {
     if (clear_stream) { (void)hipStreamDestroy(clear_stream); clear_stream = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+    if (ev_junc_done) { (void)hipEventDestroy(ev_junc_done); ev_junc_done = nullptr; }
+    if (junc_stream) { (void)hipStreamDestroy(junc_stream); junc_stream = nullptr; }
 }
 
 // Replaces ChrMapUpdate of all processors: binds reference-table chromosomes to
@@ -821,7 +834,7 @@ int irf_ctx::wait(uint64_t id) {
 
 // one IR table: t = 0 non-directional (both strands), t = 1 directional under `dirn`
 // (dual: both tables in one pass over the planes — table 0 into d_out_*[0], the directional one into d_out_*[1])
-void irf_ctx::launch_stats(int t, int dirn, bool dual) {
+dev::IntronTables irf_ctx::intron_tables(int t, int dirn, bool dual) {
     dev::IntronTables T;
     memset(&T, 0, sizeof T);
     T.n_intron = n_intron; T.n_sp = n_sp; T.plane_stride = plane_stride; T.diff = d_diff.p; T.carry = d_carry.p;
@@ -840,7 +853,11 @@ void irf_ctx::launch_stats(int t, int dirn, bool dual) {
     T.out_f64 = d_out_f64[t].p; T.out_u32 = d_out_u32[t].p; T.err_flags = d_err.p;
     T.dual = dual ? 1u : 0u;
     if (dual) { T.out_f64 = d_out_f64[0].p; T.out_u32 = d_out_u32[0].p; T.out_f64_b = d_out_f64[1].p; T.out_u32_b = d_out_u32[1].p; }
-    dev::launch_intron_stats(T, stats_classes, stream);
+    return T;
+}
+
+void irf_ctx::launch_stats(int t, int dirn, bool dual) {
+    dev::launch_intron_stats(intron_tables(t, dirn, dual), stats_classes, stream);
 }
 
 int irf_ctx::finalize() {
@@ -888,6 +905,27 @@ int irf_ctx::finalize() {
     n_unique = 0;
     d_sorted = d_junc_a.p;
     uint32_t n_radix_passes = 0;
+    // JunctionCount::Directional() (OQ-5): known junctions only, so the vote is in
+    directionality = 0;
+    if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
+    else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
+    // ---- per-intron statistics ----
+    // The statistics kernels (1.9 ms of plane reads at 50 M pairs) need nothing from the novel junctions except in the last
+    // columns of a row, and the sort-reduce of the novel junctions is ~40 small kernels and two host round trips that
+    // leave the device idle: the statistics start now, the sort runs next to them on its own stream, and launch_ir_rows
+    // writes the junction-dependent columns of the rows when both have finished.
+    HIP_TRY(hipEventRecord(ev[4], stream));
+    if (directionality != 0) launch_stats(0, directionality, true);      // both IR tables from one pass over the planes
+    else launch_stats(0, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[5], stream));
+    struct StreamSwap {            // (the code below says `stream`: it runs on the junction stream until this goes out of scope)
+        hipStream_t& ref; hipStream_t saved;
+        StreamSwap(hipStream_t& r, hipStream_t to) : ref(r), saved(r) { ref = to; }
+        ~StreamSwap() { ref = saved; }
+    };
+    {
+    StreamSwap on_junction_stream(stream, junc_stream);
     if (n_events) {
         // (sized to the records there are, not to the buffer's capacity: a few hundred thousand after the per-chunk merge)
         if (d_junc_b.reserve(n_events) != hipSuccess || d_juncw_b.reserve(n_events) != hipSuccess || d_wex.reserve(n_events) != hipSuccess)
@@ -931,15 +969,15 @@ int irf_ctx::finalize() {
         // ---- SpliceLeft / SpliceRight contributions of the novel junctions ----
         J.ukeys = d_ukeys.p; J.ucount = d_ucount.p; J.n_unique = n_unique;
         dev::launch_junction_lookups(J, stream);
+        HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipEventRecord(ev_junc_done, stream));
+    }
+    // ---- the junction-dependent columns of the rows ----
+    HIP_TRY(hipStreamWaitEvent(stream, ev_junc_done, 0));
     HIP_TRY(hipEventRecord(ev[2], stream));
-    // JunctionCount::Directional() (OQ-5)
-    directionality = 0;
-    if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
-    else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
-    // ---- per-intron statistics and IR rows ----
-    if (directionality != 0) launch_stats(0, directionality, true);      // both IR tables from one pass over the planes
-    else launch_stats(0, 0);
+    if (directionality != 0) dev::launch_ir_rows(intron_tables(0, directionality, true), stream);
+    else dev::launch_ir_rows(intron_tables(0, 0, false), stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], stream));
     if (plane_stride && !alt_clean) {
@@ -969,9 +1007,12 @@ int irf_ctx::finalize() {
     timing.n_radix_passes = n_radix_passes;
     timing.n_sort_records = n_events;
     if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) timing.scan_ms = ms;
-    if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) timing.junction_ms = ms;
-    if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.stats_ms = ms;
-    timing.table_ms = 0;       // the IR rows are written by the statistics kernel itself
+    // (junction_ms: known-junction lookups and the vote, up to the start of the statistics kernels, + the sort-reduce of the
+    //  novel junctions, which runs NEXT TO the statistics kernels: the two overlap, their sum is not a wall time)
+    if (hipEventElapsedTime(&ms, ev[1], ev[4]) == hipSuccess) timing.junction_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[4], ev_junc_done) == hipSuccess) timing.junction_ms += ms;
+    if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) timing.stats_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.table_ms = ms;       // launch_ir_rows
     if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) timing.total_finalize_ms = ms;
     finalized = true;
     results_ready = false;

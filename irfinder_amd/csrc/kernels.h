@@ -262,6 +262,10 @@ struct IntronTables {
     uint32_t* err_flags;
 };
 void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s);
+// The junction-dependent columns of the rows (SpliceLeft / SpliceRight / SpliceExact, IRratio, the warning) once more,
+// from the depth columns launch_intron_stats has written: irf_finalize starts the statistics kernels before the
+// novel-junction table is finished (T.n_unique = 0 there) and runs this afterwards with the finished tables.
+void launch_ir_rows(const IntronTables& T, hipStream_t s);
 
 }   // namespace dev
 }   // namespace irf

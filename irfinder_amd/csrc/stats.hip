@@ -835,7 +835,78 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
 #endif
 }
 
+// One thread per intron: the row tail of intron_stats_kernel (same expressions, same order) on the finished junction
+// tables.  Reads Depth / flank medians back from the table, writes the five counters, IRratio and the warning.
+__global__ __launch_bounds__(256) void ir_rows_kernel(IntronTables T) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= T.n_intron) return;
+    const IntronRec R = T.recs[k];
+    const bool valid = (R.flags & 1u) != 0u;
+    const bool counters = valid && !(T.ablate & 2u);
+    uint32_t cnt[5][2];
+    {
+        const int32_t ix[5] = {R.sp_s, R.sp_e, R.us, R.ue, R.kj};
+        const uint32_t* base[5] = {T.sp_cnt, T.sp_cnt, T.left_cnt, T.right_cnt, T.known_cnt};
+        const uint64_t n[5] = {T.n_sp, T.n_sp, T.n_ustart, T.n_uend, T.n_kj};
+#pragma unroll
+        for (int w = 0; w < 5; w++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) cnt[w][h] = (counters && ix[w] >= 0) ? base[w][(uint64_t)h * n[w] + (uint64_t)ix[w]] : 0u;
+    }
+    // novel junctions on (Start, End), per strand
+    uint32_t nov[2] = {0u, 0u};
+    if (counters && R.kj < 0) {
+        const uint64_t span = R.g_end - R.g_start;
+        if (span < (1ull << kJuncSpanBits) && R.g_start < kJuncMaxGlobal && T.n_unique > 0) {
+            const uint64_t key0 = (R.g_start << kJuncLeftShift) | (span << 1);
+            uint64_t lo_i = 0, hi_i = T.n_unique;
+            while (lo_i < hi_i) {
+                const uint64_t mid = lo_i + ((hi_i - lo_i) >> 1);
+                if (T.ukeys[mid] < key0) lo_i = mid + 1; else hi_i = mid;
+            }
+            for (uint64_t u = lo_i; u < T.n_unique && u < lo_i + 2 && (T.ukeys[u] >> 1) == (key0 >> 1); u++) nov[T.ukeys[u] & 1ull] += T.ucount[u];
+        }
+    }
+    const int plane_strand = (((R.flags & 2u) != 0) == (T.directionality > 0)) ? 1 : 0;
+    const int n_tables = T.dual ? 2 : 1;
+    const uint64_t n = T.n_intron, i = R.row;
+    for (int t = 0; t < n_tables; t++) {
+        const int plane = T.dual ? (t == 0 ? 2 : plane_strand) : (T.directionality != 0 ? plane_strand : 2);
+        double* __restrict__ out_f64 = t == 0 ? T.out_f64 : T.out_f64_b;
+        uint32_t* __restrict__ out_u32 = t == 0 ? T.out_u32 : T.out_u32_b;
+        auto pick = [&](const uint32_t* c) -> uint32_t { return plane == 2 ? c[0] + c[1] : (plane == 1 ? c[1] : c[0]); };
+        const uint32_t spl = pick(cnt[0]), spr = pick(cnt[1]), jl = pick(cnt[2]), jr = pick(cnt[3]);
+        const uint32_t je = pick(cnt[4]) + pick(nov);
+        const double depth = out_f64[1 * n + i], flank0 = out_f64[5 * n + i], flank1 = out_f64[6 * n + i];
+        const uint32_t smax = jl > jr ? jl : jr;
+        const double den = depth + (double)smax;
+        const double irratio = den > 0.0 ? depth / den : 0.0;
+        const double sp_max = (double)(spl > spr ? spl : spr);
+        const double fl_max = flank0 > flank1 ? flank0 : flank1;
+        const double maxflank = sp_max > fl_max ? sp_max : fl_max;
+        uint32_t warn;
+        if ((double)je + depth < T.warn_lowcover_min) warn = 1;
+        else if ((double)je < T.warn_lowsplice_min) warn = 2;
+        else if ((double)je * T.warn_minor_ratio < (double)smax) warn = 3;
+        else if (T.warn_nonuniform_and ? (maxflank > depth + T.warn_nonuniform_abs && maxflank > depth * T.warn_nonuniform_rel)
+                                       : (maxflank > depth * T.warn_nonuniform_rel + T.warn_nonuniform_abs)) warn = 4;
+        else warn = 0;
+        out_f64[7 * n + i] = irratio;
+        out_u32[0 * n + i] = spl;
+        out_u32[1 * n + i] = spr;
+        out_u32[2 * n + i] = jl;
+        out_u32[3 * n + i] = jr;
+        out_u32[4 * n + i] = je;
+        out_u32[5 * n + i] = warn;
+    }
+}
+
 }   // namespace
+
+void launch_ir_rows(const IntronTables& T, hipStream_t s) {
+    if (!T.n_intron) return;
+    hipLaunchKernelGGL(ir_rows_kernel, dim3((T.n_intron + 255u) / 256u), dim3(256), 0, s, T);
+}
 
 // T.recs is laid out by size class (kernels.h: StatsClasses) and, inside a class, by workgroup: workgroup w of class c
 // walks records [wg_off[c][w], wg_off[c][w + 1]) (the host balanced the lists).  The 64-thread class keeps its flank
