@@ -142,6 +142,9 @@ __device__ __forceinline__ void seg_add(const CountTables& T, uint32_t dir, uint
     __hip_atomic_fetch_add(T.seg_sum + (uint64_t)dir * (T.plane_stride >> kSegShift) + (c >> kSegShift), (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (CountTables.dirty: the line of plane position c of strand dir now holds something)
+__device__ __forceinline__ void mark_dirty(const CountTables& T, uint32_t dir, uint64_t c) { T.dirty[((c >> 4) << 1) + dir] = 1; }
+
 __device__ __forceinline__ uint64_t plane_of(const CountTables& T, uint32_t m, uint64_t g) {
     if (!T.pmap) return g;
     const uint64_t c = (uint64_t)(m >> 1) << kBucketShift;
@@ -153,6 +156,7 @@ __device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use
 #ifdef K_NOLINES
     __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seg_add(T, dir, c, v);
+    mark_dirty(T, dir, c);
     return;
 #endif
     // (a line holds both strands, packed like the window: unstranded reads put both on the same positions, so this is
@@ -167,6 +171,7 @@ __device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use
     if (!mine) {
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_add(T, dir, c, v);
+        mark_dirty(T, dir, c);
     }
 }
 
@@ -641,6 +646,8 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             const int32_t s0 = row_sum_dpp(v0), s1 = row_sum_dpp(v1);
             if (cell == 15u && s0) seg_add(T, 0u, c, s0);
             if (cell == 15u && s1) seg_add(T, 1u, c, s1);
+            // (a claimed line is marked for both strands whatever it holds: marking too much only costs the clear a line)
+            if (cell == 15u && tag != kEmpty) *reinterpret_cast<uint16_t*>(T.dirty + ((uint64_t)tag << 1)) = 0x0101u;
         }
         for (uint32_t e0 = 0; e0 <= wtop; e0 += kThreads) {
             const uint32_t e = e0 + tid;                                // < kWin: the window is a multiple of the workgroup
@@ -658,6 +665,8 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
             if (lane == 63u) {
                 if (s0) seg_add(T, 0u, win + e, s0);
                 if (s1) seg_add(T, 1u, win + e, s1);
+                // the wave's four lines, both strands: eight consecutive marks (the window starts on a multiple of 64)
+                *reinterpret_cast<unsigned long long*>(T.dirty + (((win + e) >> 6) << 3)) = 0x0101010101010101ull;
             }
         }
         __syncthreads();
@@ -716,6 +725,37 @@ __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cr, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_add(T, dir, cl, -c);
         seg_add(T, dir, cr, c);
+        mark_dirty(T, dir, cl);
+        mark_dirty(T, dir, cr);
+    }
+}
+
+// Zeroes the marked lines of the planes and the marks.  A lane reads 16 marks (a wave: 1024 marks = 512 lines of both
+// strands, one coalesced load); the groups that hold a mark are then taken one at a time by the whole wave, four lanes
+// per mark (16 bytes each of the 64-byte line), so that the stores of a group cover whole lines next to each other.
+__global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* __restrict__ planes, uint8_t* dirty, uint64_t plane_stride, uint64_t n_groups) {
+    typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t g0 = (((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6) << 6;      // the wave's first group
+    if (g0 >= n_groups) return;
+    const uint64_t g = g0 + lane;
+    uint4 m = make_uint4(0u, 0u, 0u, 0u);
+    if (g < n_groups) m = reinterpret_cast<const uint4*>(dirty)[g];
+    const bool any = (m.x | m.y | m.z | m.w) != 0u;
+    uint64_t todo = __ballot(any);
+    if (any) reinterpret_cast<uint4*>(dirty)[g] = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t q = lane >> 4, sh = ((lane >> 2) & 3u) * 8u;
+    while (todo) {
+        const int s = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane((int)m.x, s), my = (uint32_t)__builtin_amdgcn_readlane((int)m.y, s),
+                       mz = (uint32_t)__builtin_amdgcn_readlane((int)m.z, s), mw = (uint32_t)__builtin_amdgcn_readlane((int)m.w, s);
+        const uint32_t w = q == 0u ? mx : (q == 1u ? my : (q == 2u ? mz : mw));
+        if ((w >> sh) & 0xffu) {
+            const uint64_t mark = (g0 + (uint64_t)s) * 16u + (lane >> 2);
+            const uint64_t line = mark >> 1, dir = mark & 1u;
+            *reinterpret_cast<V4*>(planes + dir * plane_stride + line * 16u + (lane & 3u) * 4u) = V4{0u, 0u, 0u, 0u};
+        }
     }
 }
 
@@ -724,6 +764,14 @@ __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T
 void launch_known_junction_depth(const CountTables& T, hipStream_t s) {
     if (T.n_known == 0) return;
     hipLaunchKernelGGL(known_junction_depth_kernel, dim3((T.n_known + 255u) / 256u), dim3(256), 0, s, T);
+}
+
+void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride, hipStream_t s) {
+    const uint64_t n_groups = dirty_map_bytes(plane_stride) / 16u;
+    if (!n_groups) return;
+    // (short-lived workgroups, 4096 marks each: the clear runs on a stream of the lowest priority next to the table
+    //  export's copy kernels, which take the slots as they come free)
+    hipLaunchKernelGGL(sparse_clear_kernel, dim3((uint32_t)((n_groups + 255u) / 256u)), dim3(256), 0, s, planes, dirty, plane_stride, n_groups);
 }
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {

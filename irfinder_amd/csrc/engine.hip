@@ -99,6 +99,7 @@ struct irf_ctx {
     DevBuf<uint32_t> d_seg_sum;                  // [2][plane_stride/256] sum of each segment of d_diff (count kernel)
     // A second set of planes for the NEXT sample: cleared on a side stream once this sample's statistics kernels are done
     // (while the host fetches the tables the GPU has nothing else to do), so irf_reset swaps instead of clearing in line.
+    DevBuf<uint8_t> d_dirty, d_dirty_alt;        // which 64-byte lines of d_diff / d_diff_alt hold something (kernels.h: CountTables.dirty)
     DevBuf<int32_t> d_diff_alt;
     DevBuf<uint32_t> d_seg_sum_alt;
     hipStream_t clear_stream = nullptr;
@@ -246,13 +247,13 @@ int irf_ctx::init() {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&clear_stream, hipStreamNonBlocking));
     {
         // the sort's many small kernels run while the statistics kernels fill the device: highest priority, so that they
         // get the next free slot
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_TRY(hipStreamCreateWithPriority(&junc_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&clear_stream, hipStreamNonBlocking, least));      // (yields to the export's copy kernels)
         HIP_TRY(hipEventCreate(&ev_junc_done));
     }
     HIP_TRY(hipEventCreateWithFlags(&ev_stats_done, hipEventDisableTiming));
@@ -363,9 +364,10 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     TRY(upload(this, d_chr_owned, chr_owned));
     {
         if (clear_stream) HIP_TRY(hipStreamSynchronize(clear_stream));
-        d_diff_alt.release(); d_seg_sum_alt.release();      // (a new map: the spare planes are allocated again when first needed)
+        d_diff_alt.release(); d_seg_sum_alt.release(); d_dirty_alt.release();      // (a new map: the spare planes are allocated again when first needed)
         alt_clean = false;
         hipError_t e = d_diff.reserve(2 * plane_stride);
+        if (e == hipSuccess) e = d_dirty.reserve(dev::dirty_map_bytes(plane_stride));
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth planes failed");
     }
     TRY(alloc_zero(this, d_chr_cnt, (size_t)n * 2));
@@ -667,11 +669,13 @@ int irf_ctx::zero_counters() {
         // the spare planes were cleared behind the last sample's statistics: take them
         d_diff.swap(d_diff_alt);
         d_seg_sum.swap(d_seg_sum_alt);
+        d_dirty.swap(d_dirty_alt);
         HIP_TRY(hipStreamWaitEvent(stream, ev_cleared, 0));
         alt_clean = false;
     } else {
         if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
         if (plane_stride) HIP_TRY(hipMemsetAsync(d_seg_sum.p, 0, 2 * plane_stride / dev::kDepthSegment * sizeof(uint32_t), stream));
+        if (plane_stride) HIP_TRY(hipMemsetAsync(d_dirty.p, 0, dev::dirty_map_bytes(plane_stride), stream));
     }
     if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
     if (n_roi) HIP_TRY(hipMemsetAsync(d_roi_cnt.p, 0, (size_t)n_roi * 2 * sizeof(uint32_t), stream));
@@ -703,7 +707,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.plane_stride = plane_stride; T.full_size = full_size; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
     T.junc_capacity = d_junc_a.cap;
     T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
-    T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.chr_cnt = d_chr_cnt.p;
+    T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.dirty = d_dirty.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p; T.roi_bucket = d_roi_bucket.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
     T.sp_pos32 = d_sp_pos32.p; T.n_sp_dev = (uint32_t)n_sp_dev; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
@@ -984,16 +988,26 @@ int irf_ctx::finalize() {
         // the next sample's planes: cleared on the side stream as soon as the statistics kernels have finished (a memset
         // UNDER them costs them more than its own time; behind them the device is idle while the host fetches the tables)
         const size_t n_seg2 = 2 * plane_stride / dev::kDepthSegment;
-        if (d_diff_alt.reserve(2 * plane_stride) == hipSuccess && d_seg_sum_alt.reserve(n_seg2) == hipSuccess) {
+        const bool had_spare = d_diff_alt.cap >= 2 * plane_stride && d_dirty_alt.cap >= dev::dirty_map_bytes(plane_stride);
+        if (d_diff_alt.reserve(2 * plane_stride) == hipSuccess && d_seg_sum_alt.reserve(n_seg2) == hipSuccess &&
+            d_dirty_alt.reserve(dev::dirty_map_bytes(plane_stride)) == hipSuccess) {
             HIP_TRY(hipEventRecord(ev_stats_done, stream));
             HIP_TRY(hipStreamWaitEvent(clear_stream, ev_stats_done, 0));
-            HIP_TRY(hipMemsetAsync(d_diff_alt.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
+            if (had_spare) {
+                // the spare planes were this context's planes one sample ago: only the lines that sample marked hold anything
+                // (a third of them at 50 M pairs)
+                dev::launch_sparse_clear(d_diff_alt.p, d_dirty_alt.p, plane_stride, clear_stream);
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipMemsetAsync(d_diff_alt.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
+                HIP_TRY(hipMemsetAsync(d_dirty_alt.p, 0, dev::dirty_map_bytes(plane_stride), clear_stream));
+            }
             HIP_TRY(hipMemsetAsync(d_seg_sum_alt.p, 0, n_seg2 * sizeof(uint32_t), clear_stream));
             HIP_TRY(hipEventRecord(ev_cleared, clear_stream));
             alt_clean = true;
         } else {
             (void)hipGetLastError();           // no room for a second set: the planes are cleared in line, as before
-            d_diff_alt.release(); d_seg_sum_alt.release();
+            d_diff_alt.release(); d_seg_sum_alt.release(); d_dirty_alt.release();
         }
     }
     HIP_TRY(hipStreamSynchronize(stream));

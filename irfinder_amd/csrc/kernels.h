@@ -87,6 +87,10 @@ struct CountTables {
     uint32_t* junc_w;             // ... and their weights (a chunk's events on one junction are merged in LDS first)
     unsigned long long* junc_count;
     uint32_t* err_flags;
+    // One byte per 64-byte line of the planes ([plane_stride / 16][2 strands]): set by whatever adds to the line (or may
+    // have).  The planes of a sample are mostly untouched lines (introns at low depth), so clearing them for the next
+    // sample (launch_sparse_clear) writes the marked lines only instead of all of them.
+    uint8_t* dirty;
 };
 
 struct BatchDev {
@@ -105,6 +109,9 @@ void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s);
 // difference events of the reads on known junctions, from the junction counters: after the sample's last count kernel,
 // before the carry scan (once per sample)
 void launch_known_junction_depth(const CountTables& T, hipStream_t s);
+// zeroes the lines of planes[2][plane_stride] that dirty[] marks, and the marks (dirty: dirty_map_bytes(plane_stride) bytes)
+void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride, hipStream_t s);
+inline size_t dirty_map_bytes(uint64_t plane_stride) { return (size_t)((plane_stride / 16 * 2 + 15) / 16 * 16); }
 
 // ---- scans ----------------------------------------------------------------
 constexpr uint32_t kScanTile = 4096;
