@@ -264,7 +264,10 @@ int irf_export_device(irf_ctx* ctx, uint32_t what, void* dst_device, uint64_t* n
 #define IRF_COL_KEEP_ORPHANS 0x100u
 /* `dst_device` of irf_export_device may also be PAGE-LOCKED HOST memory (irf_host_alloc): the column then crosses PCIe
  * once, without a device-side copy (not for the IR tables of a sharded context).  With IRF_COL_NO_SYNC OR-ed into `what`
- * the copy is only queued on the context's stream: call irf_sync before reading `dst` (several columns, one wait).  */
+ * the copy is only queued: call irf_sync before reading `dst` (several columns, one wait).  The queued copies of the IR
+ * tables of an unsharded context run on a stream of their own: irf_reset / irf_submit_batch of the NEXT sample may be
+ * called before irf_sync, and its count kernel then runs while the tables cross PCIe (the library orders the next
+ * write of its tables behind the copy; give every sample in flight its own `dst`).                                    */
 #define IRF_COL_NO_SYNC 0x200u
 
 /* ------------------------------------------------------------------------ */
@@ -306,10 +309,12 @@ int irf_get_layout(irf_ctx* ctx, irf_layout* out);
  * submit/finalize cycle, measured with HIP events on the engine's stream.   */
 typedef struct irf_timing {
     float count_ms;      /* sum over batches of the fused count kernel       */
-    float scan_ms;
-    float stats_ms;
-    float junction_ms;
-    float table_ms;
+    float scan_ms;       /* known-junction depth events + scan of the depth carries                             */
+    float stats_ms;      /* the per-intron statistics kernels                                                   */
+    float junction_ms;   /* known-junction lookups + vote, then the sort-reduce of the novel junctions: the
+                            latter runs on its own stream NEXT TO the statistics kernels, so this interval
+                            overlaps stats_ms (the stages' sum is more than total_finalize_ms)                  */
+    float table_ms;      /* the junction-dependent columns of the IR rows, written when both have finished      */
     float total_finalize_ms;
     uint32_t n_count_launches;
     uint32_t n_radix_passes;   /* 8-bit digit passes the novel-junction sort ran (digits equal in every key are skipped) */

@@ -76,6 +76,15 @@ struct irf_ctx {
     RefTables ref;
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
+    // IRF_COL_NO_SYNC exports of the IR tables run on their own stream: the tables of sample k cross PCIe while the count
+    // kernel of sample k+1 runs (whatever writes the tables next waits for them: order_after_exports)
+    hipStream_t export_stream = nullptr;
+    hipEvent_t ev_tables_ready = nullptr, ev_export_done = nullptr;
+    bool exports_pending = false;
+    int order_after_exports() {
+        if (exports_pending) { HIP_TRY(hipStreamWaitEvent(stream, ev_export_done, 0)); exports_pending = false; }
+        return 0;
+    }
     hipStream_t junc_stream = nullptr;           // the novel-junction sort of irf_finalize, next to the statistics kernels
     hipEvent_t ev_junc_done = nullptr;
     std::string err;
@@ -255,6 +264,9 @@ int irf_ctx::init() {
         HIP_TRY(hipStreamCreateWithPriority(&junc_stream, hipStreamNonBlocking, greatest));
         HIP_TRY(hipStreamCreateWithPriority(&clear_stream, hipStreamNonBlocking, least));      // (yields to the export's copy kernels)
         HIP_TRY(hipEventCreate(&ev_junc_done));
+        HIP_TRY(hipStreamCreateWithFlags(&export_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_tables_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_export_done, hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&ev_stats_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_cleared, hipEventDisableTiming));
@@ -282,6 +294,9 @@ void irf_ctx::free_events() {
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
     if (ev_junc_done) { (void)hipEventDestroy(ev_junc_done); ev_junc_done = nullptr; }
+    if (export_stream) { (void)hipStreamSynchronize(export_stream); (void)hipStreamDestroy(export_stream); export_stream = nullptr; }
+    if (ev_tables_ready) { (void)hipEventDestroy(ev_tables_ready); ev_tables_ready = nullptr; }
+    if (ev_export_done) { (void)hipEventDestroy(ev_export_done); ev_export_done = nullptr; }
     if (junc_stream) { (void)hipStreamDestroy(junc_stream); junc_stream = nullptr; }
 }
 
@@ -918,6 +933,7 @@ int irf_ctx::finalize() {
     // columns of a row, and the sort-reduce of the novel junctions is ~40 small kernels and two host round trips that
     // leave the device idle: the statistics start now, the sort runs next to them on its own stream, and launch_ir_rows
     // writes the junction-dependent columns of the rows when both have finished.
+    TRY(order_after_exports());
     HIP_TRY(hipEventRecord(ev[4], stream));
     if (directionality != 0) launch_stats(0, directionality, true);      // both IR tables from one pass over the planes
     else launch_stats(0, 0);
@@ -1043,6 +1059,7 @@ int irf_ctx::finalize_directional(int32_t dirn) {
     directionality = dirn;
     ir_prepared[1] = false;
     if (dirn != 0) {
+        TRY(order_after_exports());
         launch_stats(1, dirn);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1176,6 +1193,15 @@ int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
             return fail(IRF_E_ARG, "irf_export_device: the IR tables of a sharded context are exported into DEVICE memory (their foreign rows are zeroed there)");
         }
     }
+    if (table >= 0 && !sharded && no_sync) {
+        // an IR table, copy only queued: on the export stream, behind everything queued on the main stream so far
+        HIP_TRY(hipEventRecord(ev_tables_ready, stream));
+        HIP_TRY(hipStreamWaitEvent(export_stream, ev_tables_ready, 0));
+        HIP_TRY(hipMemcpyAsync(dst, src, n * elem, hipMemcpyDefault, export_stream));
+        HIP_TRY(hipEventRecord(ev_export_done, export_stream));
+        exports_pending = true;
+        return 0;
+    }
     HIP_TRY(hipMemcpyAsync(dst, src, n * elem, hipMemcpyDefault, stream));       // dst: device memory, or page-locked host memory
     if (table >= 0 && sharded) {
         const uint32_t keep = (1u << dev::kRowMine) | (keep_orphans ? (1u << dev::kRowOrphan) : 0u);
@@ -1212,6 +1238,7 @@ int irf_ctx::import_col(uint32_t what, const void* src, uint64_t n) {
     }
     if (n != want) return fail(IRF_E_ARG, "irf_import_device: element count does not match this context's table");
     if (!n) return 0;
+    TRY(order_after_exports());
     if (table >= 0 && !ir_prepared[table]) {
         const uint32_t keep = (1u << dev::kRowMine) | (1u << dev::kRowOrphan);
         dev::launch_mask_rows_f64(d_out_f64[table].p, 8, n_intron, d_row_code.p, keep, stream);
@@ -1363,7 +1390,9 @@ int irf_submit_batch(irf_ctx* c, const irf_batch* b, uint64_t* id) { return c ? 
 int irf_wait(irf_ctx* c, uint64_t id) { return c ? c->wait(id) : IRF_E_ARG; }
 int irf_sync(irf_ctx* c) {
     if (!c) return IRF_E_ARG;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(IRF_E_DEVICE, "irf_sync: stream synchronize failed");
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+        (c->export_stream && hipStreamSynchronize(c->export_stream) != hipSuccess)) return c->fail(IRF_E_DEVICE, "irf_sync: stream synchronize failed");
+    c->exports_pending = false;
     return 0;
 }
 int irf_finalize(irf_ctx* c) { return c ? c->finalize() : IRF_E_ARG; }

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import orc
-from irfinder_amd import engine
+from irfinder_amd import _abi, engine
 from irfinder_amd._abi import Batch
 from irfinder_amd.synth.bam import records_to_bam
 from util import assert_results_equal, small_world
@@ -251,6 +251,42 @@ def test_empty_and_reset():
     e.finalize()
     o, c = run_orc(ann.ref_texts(), names, lens, [b2])
     assert_results_equal(e.results(), c, rel=0.0, what="second sample")
+
+
+def test_queued_table_exports_overlap_the_next_sample():
+    """IRF_COL_NO_SYNC exports of the IR tables run on the library's export stream: the next sample is reset, submitted and
+    finalized without an irf_sync in between (include/irf.h).  Three samples through one context, every table into its own
+    page-locked buffer, one irf_sync at the end: every table equals the oracle's for ITS sample (a copy that ran late
+    would hold the next sample's rows; planes that were not cleared, the previous sample's depth)."""
+    import torch
+    ann, sim = small_world(seed=4)
+    names, lens, _ = read_batch(sim.bam(0, 100))
+    samples = [read_batch(sim.bam(a, n))[2] for a, n in ((0, 20000), (20000, 6000), (30000, 12000))]
+    ref = engine.RefTables.from_texts(ann.ref_texts())
+    e = engine.Engine(ref)
+    e.chr_map_update(names, lens)
+    n_in = ann.cover_bed.count("\n")
+    bufs = []
+    for b in samples:
+        e.reset()
+        e.process(b)
+        e.finalize()
+        f64 = torch.empty((8, n_in), dtype=torch.float64, pin_memory=True)
+        u32 = torch.empty((6, n_in), dtype=torch.int32, pin_memory=True)
+        f64.fill_(-1.0); u32.fill_(-1)
+        e.export_device(_abi.COL_IR_NONDIR_F64 | _abi.COL_NO_SYNC, f64.data_ptr())
+        e.export_device(_abi.COL_IR_NONDIR_U32 | _abi.COL_NO_SYNC, u32.data_ptr())
+        bufs.append((f64, u32))
+    e.sync()
+    for k, b in enumerate(samples):
+        o, c = run_orc(ann.ref_texts(), names, lens, [b])
+        nd = c["nondir"]
+        f64, u32 = bufs[k][0].numpy(), bufs[k][1].numpy().view(np.uint32)
+        for j, col in enumerate(_abi.IR_F64):
+            assert np.array_equal(f64[j], np.asarray(nd[col], np.float64)), (k, col)
+        for j, col in enumerate(_abi.IR_U32 + ("warning",)):
+            assert np.array_equal(u32[j], np.asarray(nd[col]).astype(np.uint32)), (k, col)
+        assert (f64[1] > 0).sum() > 3, k
 
 
 def test_diagnostic_environment_switches_do_not_reach_the_product(monkeypatch):
