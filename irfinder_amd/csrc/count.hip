@@ -710,16 +710,35 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
 // Every read on a known junction skipped two difference events in the count kernel (the end of the block before the
 // junction, the start of the block after it): they are applied here, once per junction and strand, from the junction's
 // counter.  Must run after the last count kernel of the sample and before the carries are scanned.
+// The kernel also takes the strandedness vote (JunctionCount::Directional, OQ-5: known junctions only): irf_finalize
+// needs it before it can start the statistics kernels, and this is the first pass over the junction counters.
 __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= T.n_known || (T.ablate & (1u | 64u))) return;
+    const bool in = i < T.n_known;
+    const uint32_t ii = in ? i : 0u;
+    const uint32_t row = T.known_kjidx[ii];
+    int cnt[2];
+    cnt[0] = in ? (int)T.known_cnt[row] : 0;
+    cnt[1] = in ? (int)T.known_cnt[(uint64_t)T.n_kj + row] : 0;
+    {
+        unsigned long long same = 0, opp = 0;
+        const uint32_t kd = T.known_dir[ii];
+        if (kd == 1u) { same = (uint32_t)cnt[0]; opp = (uint32_t)cnt[1]; }
+        else if (kd == 2u) { same = (uint32_t)cnt[1]; opp = (uint32_t)cnt[0]; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { same += __shfl_xor(same, d); opp += __shfl_xor(opp, d); }
+        if ((threadIdx.x & 63u) == 0u) {
+            if (same) atomicAdd(&T.dir_votes[0], same);
+            if (opp) atomicAdd(&T.dir_votes[1], opp);
+        }
+    }
+    if (!in || (T.ablate & (1u | 64u))) return;
     const uint64_t key = T.known_keys[i];
     const uint64_t gl = key >> kJuncSpanBits, gr = gl + (key & ((1ull << kJuncSpanBits) - 1ull));
-    const uint32_t row = T.known_kjidx[i];
     const uint64_t cl = plane_coord(T.pmap, gl), cr = plane_coord(T.pmap, gr);
 #pragma unroll
     for (uint32_t dir = 0; dir < 2u; dir++) {
-        const int c = (int)T.known_cnt[(uint64_t)dir * T.n_kj + row];
+        const int c = cnt[dir];
         if (!c) continue;
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cl, -c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cr, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -727,6 +727,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
     T.sp_pos32 = d_sp_pos32.p; T.n_sp_dev = (uint32_t)n_sp_dev; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
     T.known_keys = d_known_keys.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
+    T.known_dir = d_known_dir.p; T.dir_votes = d_scalars.p + 3;
     T.junc_keys = d_junc_a.p; T.junc_w = d_juncw_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
     return T;
 }
@@ -895,19 +896,7 @@ int irf_ctx::finalize() {
     if (env_u64("IRF_RESCAN_PLANES", 0)) dev::launch_segment_sums(d_diff.p, 2 * plane_stride, d_seg_sum.p, stream);     // diagnostic: recompute the sums from the planes
     dev::launch_exclusive_scan_u32(d_seg_sum.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[1], stream));
-    if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));
-    if (n_ue) HIP_TRY(hipMemsetAsync(d_right_cnt.p, 0, (size_t)n_ue * 2 * 4, stream));
-    HIP_TRY(hipMemsetAsync(d_scalars.p + 3, 0, 2 * sizeof(unsigned long long), stream));
-    dev::JuncLookupTables J;
-    memset(&J, 0, sizeof J);
-    J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
-    J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
-    J.known_keys = d_known_keys.p; J.known_kjidx = d_known_kjidx.p; J.known_dir = d_known_dir.p;
-    J.known_us_idx = d_known_us_idx.p; J.known_ue_idx = d_known_ue_idx.p;
-    J.n_known = n_known_dev; J.n_kj = n_kj; J.known_cnt = d_known_cnt.p;
-    J.dir_votes = d_scalars.p + 3;
-    dev::launch_known_lookups(J, stream);
-    // ---- junction events -> sorted unique table ----
+    // (the vote came with the known-junction depth events: irf_reset zeroed the two sums, the kernel runs once per sample)
     unsigned long long scal[8];
     uint32_t errf = 0;
     HIP_TRY(hipMemcpyAsync(scal, d_scalars.p, sizeof scal, hipMemcpyDeviceToHost, stream));
@@ -946,6 +935,20 @@ int irf_ctx::finalize() {
     };
     {
     StreamSwap on_junction_stream(stream, junc_stream);
+    // ---- SpliceLeft / SpliceRight contributions of the known junctions ----
+    if (n_us) HIP_TRY(hipMemsetAsync(d_left_cnt.p, 0, (size_t)n_us * 2 * 4, stream));
+    if (n_ue) HIP_TRY(hipMemsetAsync(d_right_cnt.p, 0, (size_t)n_ue * 2 * 4, stream));
+    dev::JuncLookupTables J;
+    memset(&J, 0, sizeof J);
+    J.ustart_pos = d_us_pos.p; J.uend_pos = d_ue_pos.p; J.n_ustart = n_us; J.n_uend = n_ue;
+    J.left_cnt = d_left_cnt.p; J.right_cnt = d_right_cnt.p;
+    J.known_keys = d_known_keys.p; J.known_kjidx = d_known_kjidx.p; J.known_dir = d_known_dir.p;
+    J.known_us_idx = d_known_us_idx.p; J.known_ue_idx = d_known_ue_idx.p;
+    J.n_known = n_known_dev; J.n_kj = n_kj; J.known_cnt = d_known_cnt.p;
+    J.dir_votes = nullptr;
+    dev::launch_known_lookups(J, stream);
+    HIP_TRY(hipGetLastError());
+    // ---- junction events -> sorted unique table ----
     if (n_events) {
         // (sized to the records there are, not to the buffer's capacity: a few hundred thousand after the per-chunk merge)
         if (d_junc_b.reserve(n_events) != hipSuccess || d_juncw_b.reserve(n_events) != hipSuccess || d_wex.reserve(n_events) != hipSuccess)

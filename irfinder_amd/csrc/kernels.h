@@ -83,6 +83,10 @@ struct CountTables {
     uint32_t n_known;             // entries of known_keys
     uint32_t n_kj;                // rows of the known-junction table
     uint32_t* known_cnt;          // [2][n_kj]
+    // known_junction_depth_kernel only: the strand of every known_keys entry (1 '-', 2 '+', 0/3 unknown) and the two vote
+    // sums of JunctionCount::Directional (reads on a junction whose strand agrees / disagrees with their own)
+    const uint8_t* known_dir;
+    unsigned long long* dir_votes;
     uint64_t* junc_keys;          // novel-junction event buffer: packed keys ...
     uint32_t* junc_w;             // ... and their weights (a chunk's events on one junction are merged in LDS first)
     unsigned long long* junc_count;
@@ -159,7 +163,7 @@ struct JuncLookupTables {
     const int32_t* known_ue_idx;
     uint32_t n_known, n_kj;
     const uint32_t* known_cnt;   // [2][n_kj]
-    unsigned long long* dir_votes;   // [2]: same, opposite (JunctionCount::Directional)
+    unsigned long long* dir_votes;   // [2]: same, opposite (JunctionCount::Directional); nullptr: the vote was taken elsewhere
 };
 // novel unique junctions -> SpliceLeft/Right counters
 void launch_junction_lookups(const JuncLookupTables& J, hipStream_t s);

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void known_lookups_kernel(JuncLookupTable
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { same += __shfl_xor(same, d); opp += __shfl_xor(opp, d); }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && J.dir_votes) {
         if (same) atomicAdd(&J.dir_votes[0], same);
         if (opp) atomicAdd(&J.dir_votes[1], opp);
     }
