@@ -428,27 +428,39 @@ def main():
         dten_c = {n: torch.from_numpy(getattr(host_collated, n)).to(dev) for n, _ in Batch.FIELDS}
         dbatch_c = engine.device_batch(dten_c, host_collated.n_frag, host_collated.n_blk)
         n_rep = max(1, min(args.steps, 5))
-        c_ms = 0.0
-        for rep in range(n_rep + 1):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            eng.reset()
-            eng.submit(dbatch_c)
-            eng.finalize()
-            t_ir = export(COL_IR_NONDIR_F64, (8, n_in), torch.float64)
-            out["ir_f64"].copy_(t_ir, non_blocking=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            if rep:          # first pass = warm-up
-                c_ms += eng.timing()["count_ms"]
-                best_c = t1 - t0 if rep == 1 else min(best_c, t1 - t0)
-        same = bool(np.array_equal(out["ir_f64"].numpy(), out["got"]["ir_f64"].cpu().numpy()))
-        extra["order_random"] = {"ms_per_step": round(best_c * 1e3, 3), "pairs_per_s": round(args.pairs / best_c, 1),
-                                 "count_ms": round(c_ms / n_rep, 4),
-                                 "count_GBps": round(alg["count_ms"] / (c_ms / n_rep * 1e-3) / 1e9, 1) if c_ms > 0 else None,
-                                 "same_rows_as_sorted_run": same,
-                                 "note": "the same fragments in name-collated (generation) order, device-resident: the order irf_dreader_* "
-                                         "delivers; the count kernel's LDS difference window is built for coordinate-sorted input"}
+
+        def collated_leg():
+            c_ms = 0.0
+            for rep in range(n_rep + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.reset()
+                eng.submit(dbatch_c)
+                eng.finalize()
+                t_ir = export(COL_IR_NONDIR_F64, (8, n_in), torch.float64)
+                out["ir_f64"].copy_(t_ir, non_blocking=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if rep:          # first pass = warm-up
+                    c_ms += eng.timing()["count_ms"]
+                    best_c = t1 - t0 if rep == 1 else min(best_c, t1 - t0)
+            same = bool(np.array_equal(out["ir_f64"].numpy(), out["got"]["ir_f64"].cpu().numpy()))
+            return {"ms_per_step": round(best_c * 1e3, 3), "pairs_per_s": round(args.pairs / best_c, 1), "count_ms": round(c_ms / n_rep, 4),
+                    "same_rows_as_sorted_run": same}
+
+        from irfinder_amd._abi import ORDER_ANY, ORDER_SORTED
+        as_given = collated_leg()
+        eng.set_input_order(ORDER_ANY)
+        binned = collated_leg()
+        eng.set_input_order(ORDER_SORTED)
+        extra["order_random"] = dict(binned)
+        extra["order_random"].update({
+            "count_GBps": round(alg["count_ms"] / (binned["count_ms"] * 1e-3) / 1e9, 1) if binned["count_ms"] > 0 else None,
+            "counted_as_given": as_given,
+            "note": "the same fragments in name-collated (generation) order, device-resident: the order irf_dreader_* delivers.  With "
+                    "irf_set_input_order(IRF_ORDER_ANY) the batch is binned by coordinate on the device (3 radix passes + a gather of the "
+                    "columns, inside ms_per_step) and the count kernel runs on the copy (count_ms: that kernel alone); counted_as_given: "
+                    "the count kernel on the scattered fragments, its LDS difference window useless"})
         del dten_c, dbatch_c
 
     # ---------------- host decode bound (reported separately, never part of `value`) ----------------

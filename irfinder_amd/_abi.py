@@ -20,6 +20,7 @@ STATUS = {0: "IRF_OK", -1: "IRF_E_ARG", -2: "IRF_E_PARSE", -3: "IRF_E_RANGE", -4
 
 (COL_IR_NONDIR_F64, COL_IR_NONDIR_U32, COL_IR_DIR_F64, COL_IR_DIR_U32, COL_JUNC_KEYS, COL_JUNC_COUNTS,
  COL_SP_CNT, COL_ROI_CNT, COL_CHR_CNT, COL_KNOWN_CNT) = range(10)
+ORDER_SORTED, ORDER_ANY = 0, 1      # irf_set_input_order
 COL_NO_SYNC = 0x200            # the copy is only queued: Engine.sync() before reading (IRF_COL_NO_SYNC)
 COL_KEEP_ORPHANS = 0x100       # OR into an IR column id on the root rank (include/irf.h: IRF_COL_KEEP_ORPHANS)
 

@@ -108,6 +108,12 @@ struct irf_ctx {
     DevBuf<uint32_t> d_seg_sum;                  // [2][plane_stride/256] sum of each segment of d_diff (count kernel)
     // A second set of planes for the NEXT sample: cleared on a side stream once this sample's statistics kernels are done
     // (while the host fetches the tables the GPU has nothing else to do), so irf_reset swaps instead of clearing in line.
+    // irf_set_input_order(IRF_ORDER_ANY): every batch is binned by coordinate before it is counted (reorder.hip)
+    uint32_t input_order = 0;
+    DevBuf<uint64_t> ro_key_a, ro_key_b;
+    DevBuf<uint32_t> ro_idx_a, ro_idx_b, ro_nblk, ro_chr, ro_start, ro_end, ro_off, ro_bs, ro_bl;
+    DevBuf<uint8_t> ro_flags, ro_rd;
+    int reorder(dev::BatchDev& B);
     DevBuf<uint8_t> d_dirty, d_dirty_alt;        // which 64-byte lines of d_diff / d_diff_alt hold something (kernels.h: CountTables.dirty)
     DevBuf<int32_t> d_diff_alt;
     DevBuf<uint32_t> d_seg_sum_alt;
@@ -828,6 +834,7 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
         B.frag_chr = st->frag_chr.p; B.frag_flags = st->frag_flags.p; B.frag_start = st->frag_start.p; B.frag_end = st->frag_end.p;
         B.frag_blk_off = st->frag_blk_off.p; B.blk_start = st->blk_start.p; B.blk_len = st->blk_len.p; B.blk_read = st->blk_read.p;
     }
+    if (input_order == IRF_ORDER_ANY && B.n_frag > 1024u) TRY(reorder(B));       // (a batch of one chunk has nothing to gain)
     if (count_events_used == count_events.size()) {
         hipEvent_t a, z;
         HIP_TRY(hipEventCreate(&a));
@@ -842,6 +849,43 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
     if (st) HIP_TRY(hipEventRecord(st->consumed, stream));
     n_fragments += b->n_frag;
     n_blocks += b->n_blk;
+    return 0;
+}
+
+// B (device-resident columns, any order) -> the same fragments binned by coordinate, in this context's buffers.  Runs on
+// the engine's stream in front of the batch's count kernel; the buffers are reused by the next batch (same stream).
+int irf_ctx::reorder(dev::BatchDev& B) {
+    const size_t n = B.n_frag, nb = std::max<uint32_t>(B.n_blk, 1);
+    hipError_t e = ro_key_a.reserve(n);
+    if (e == hipSuccess) e = ro_key_b.reserve(n);
+    if (e == hipSuccess) e = ro_idx_a.reserve(n);
+    if (e == hipSuccess) e = ro_idx_b.reserve(n);
+    if (e == hipSuccess) e = ro_nblk.reserve(n + 1);
+    if (e == hipSuccess) e = ro_off.reserve(n + 4);
+    if (e == hipSuccess) e = ro_chr.reserve(n + 4);
+    if (e == hipSuccess) e = ro_start.reserve(n + 4);
+    if (e == hipSuccess) e = ro_end.reserve(n + 4);
+    if (e == hipSuccess) e = ro_flags.reserve(n + 4);
+    if (e == hipSuccess) e = ro_bs.reserve(nb + 4);
+    if (e == hipSuccess) e = ro_bl.reserve(nb + 4);
+    if (e == hipSuccess) e = ro_rd.reserve(nb + 4);
+    const uint64_t ws_need = std::max(dev::radix_workspace_elems(n), dev::scan_workspace_elems(n + 1));
+    if (e == hipSuccess && ws_need > d_ws_sort.cap) e = d_ws_sort.reserve(ws_need);
+    if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the batch reorder buffers failed");
+    dev::launch_reorder_keys(B, d_chr_base.p, n_chr, ro_key_a.p, ro_idx_a.p, stream);
+    uint64_t* ks = ro_key_a.p; uint64_t* kd = ro_key_b.p;
+    uint32_t* is = ro_idx_a.p; uint32_t* id = ro_idx_b.p;
+    const uint64_t top = full_size >> dev::kReorderShift;
+    for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += 8) {
+        dev::launch_radix_pass(ks, kd, is, id, n, shift, d_ws_sort.p, stream);
+        std::swap(ks, kd); std::swap(is, id);
+    }
+    dev::launch_reorder_frags(B, is, ro_chr.p, ro_flags.p, ro_start.p, ro_end.p, ro_nblk.p, d_err.p, stream);
+    dev::launch_exclusive_scan_u32(ro_nblk.p, ro_off.p, n + 1, d_ws_sort.p, stream);
+    dev::launch_reorder_blocks(B, is, ro_off.p, ro_bs.p, ro_bl.p, ro_rd.p, stream);
+    HIP_TRY(hipGetLastError());
+    B.frag_chr = ro_chr.p; B.frag_flags = ro_flags.p; B.frag_start = ro_start.p; B.frag_end = ro_end.p; B.frag_blk_off = ro_off.p;
+    B.blk_start = ro_bs.p; B.blk_len = ro_bl.p; B.blk_read = ro_rd.p;
     return 0;
 }
 
@@ -1396,6 +1440,12 @@ int irf_sync(irf_ctx* c) {
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
         (c->export_stream && hipStreamSynchronize(c->export_stream) != hipSuccess)) return c->fail(IRF_E_DEVICE, "irf_sync: stream synchronize failed");
     c->exports_pending = false;
+    return 0;
+}
+int irf_set_input_order(irf_ctx* c, uint32_t order) {
+    if (!c) return IRF_E_ARG;
+    if (order != IRF_ORDER_SORTED && order != IRF_ORDER_ANY) return c->fail(IRF_E_ARG, "irf_set_input_order: unknown order");
+    c->input_order = order;
     return 0;
 }
 int irf_finalize(irf_ctx* c) { return c ? c->finalize() : IRF_E_ARG; }

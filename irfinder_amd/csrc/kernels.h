@@ -117,6 +117,13 @@ void launch_known_junction_depth(const CountTables& T, hipStream_t s);
 void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride, hipStream_t s);
 inline size_t dirty_map_bytes(uint64_t plane_stride) { return (size_t)((plane_stride / 16 * 2 + 15) / 16 * 16); }
 
+// ---- batches in any order (reorder.hip) -------------------------------------
+constexpr int kReorderShift = 8;       // fragments are binned by (chromosome base + start) >> kReorderShift
+void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, uint32_t* idx, hipStream_t s);
+// nblk: n_frag + 1 elements (the last one 0: its exclusive scan is the new offsets array, total included)
+void launch_reorder_frags(const BatchDev& B, const uint32_t* perm, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end, uint32_t* nblk, uint32_t* err_flags, hipStream_t s);
+void launch_reorder_blocks(const BatchDev& B, const uint32_t* perm, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd, hipStream_t s);
+
 // ---- scans ----------------------------------------------------------------
 constexpr uint32_t kScanTile = 4096;
 // number of uint32 workspace elements a scan over n elements needs

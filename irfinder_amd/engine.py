@@ -102,6 +102,7 @@ def lib():
     L.irf_reader_get_stats.argtypes = [vp, C.POINTER(IrfReaderStats)]
     L.irf_cigar2block.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p, u32, C.POINTER(u32), C.POINTER(u32)]
     L.irf_sync.argtypes = [vp]
+    L.irf_set_input_order.argtypes = [vp, C.c_uint32]
     L.irf_dreader_create.argtypes = [C.POINTER(IrfParams), C.c_int, C.POINTER(vp)]
     L.irf_dreader_destroy.argtypes = [vp]
     L.irf_dreader_destroy.restype = None
@@ -419,6 +420,11 @@ class Engine:
 
     def sync(self):
         self._chk(self.L.irf_sync(self.h))
+
+    def set_input_order(self, order):
+        """ORDER_SORTED (default) or ORDER_ANY: batches in no coordinate order are binned by coordinate on the device
+        before they are counted (include/irf.h: irf_set_input_order)."""
+        self._chk(self.L.irf_set_input_order(self.h, order))
 
     def finalize(self):
         self._chk(self.L.irf_finalize(self.h))

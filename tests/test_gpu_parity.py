@@ -83,6 +83,35 @@ def test_order_and_batch_invariance_P1_P2():
     assert_results_equal(base, shuf, rel=0.0, what="permuted+split")
 
 
+@pytest.mark.parametrize("how", ["device", "host"])
+def test_input_in_any_order_is_binned_on_the_device(how):
+    """irf_set_input_order(IRF_ORDER_ANY): shuffled fragments, batches of uneven size (one of them below the threshold the
+    reorder starts at), device-resident and host batches: the oracle's tables (P1: every output is a commutative sum)."""
+    import torch
+    ann, sim = small_world(seed=6)
+    names, lens, batch = read_batch(sim.bam(0, 30000))
+    rng = np.random.default_rng(5)
+    shuffled = batch.select(rng.permutation(batch.n_frag))
+    parts = [shuffled.select(np.arange(a, b)) for a, b in ((0, 700), (700, 19000), (19000, shuffled.n_frag))]
+    ref = engine.RefTables.from_texts(ann.ref_texts())
+    e = engine.Engine(ref)
+    e.chr_map_update(names, lens)
+    e.set_input_order(_abi.ORDER_ANY)
+    keep = []
+    for p in parts:
+        if how == "device":
+            dten = {n: torch.from_numpy(np.ascontiguousarray(getattr(p, n))).to("cuda:0") for n, _ in Batch.FIELDS}
+            keep.append(dten)
+            e.submit(engine.device_batch(dten, p.n_frag, p.n_blk))
+        else:
+            e.process(p)
+    e.finalize()
+    o, c = run_orc(ann.ref_texts(), names, lens, [batch])
+    assert_results_equal(e.results(), c, rel=0.0, what="ORDER_ANY " + how)
+    with pytest.raises(engine.IrfError):
+        e.set_input_order(7)
+
+
 def test_nondir_is_pos_plus_neg_P4_and_junction_sums_P6():
     ann, sim = small_world(seed=9)
     names, lens, batch = read_batch(sim.bam(0, 15000))
@@ -127,7 +156,8 @@ def test_oq_switches(over):
     assert_results_equal(g, c, rel=0.0, what=str(over))
 
 
-def test_device_batch_with_malformed_csr_offsets_is_reported():
+@pytest.mark.parametrize("order", [0, 1])
+def test_device_batch_with_malformed_csr_offsets_is_reported(order):
     """frag_blk_off of a device-resident batch (a third-party producer) is checked by the count kernel itself: the host
     cannot read it.  Not non-decreasing / beyond n_blk / not spanning [0, n_blk] -> irf_finalize fails with IRF_E_ARG."""
     import torch
@@ -137,6 +167,7 @@ def test_device_batch_with_malformed_csr_offsets_is_reported():
     ref = engine.RefTables.from_texts(ann.ref_texts())
     e = engine.Engine(ref)
     e.chr_map_update(names, lens)
+    e.set_input_order(order)          # (ORDER_ANY: the reorder step checks the offsets before it follows them)
 
     def run_with(off):
         e.reset()

@@ -9,5 +9,5 @@ import json
 d=json.load(open("gpurun_out/${tag}_bench.json"))
 print("ms/step", d["ms_per_step"], {k:v.get("ms") for k,v in d["roofline"]["per_kernel"].items()}, "frac", d["roofline"]["frac"], d["roofline"]["kernel"])
 r=d.get("order_random") or {}
-print("random:", r.get("ms_per_step"), r.get("count_ms"), r.get("same_rows_as_sorted_run"))
+print("random:", r.get("ms_per_step"), r.get("count_ms"), r.get("same_rows_as_sorted_run"), "as given:", r.get("counted_as_given"))
 P
