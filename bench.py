@@ -170,6 +170,7 @@ def main():
         return t.view(*shape) if shape else t
 
     phase = {"reset+submit": 0.0, "finalize": 0.0, "export+gather": 0.0, "d2h": 0.0}
+    step_log = []
 
     def step():
         t_a = time.perf_counter()
@@ -246,6 +247,7 @@ def main():
         t_e = time.perf_counter()
         phase["reset+submit"] += t_b - t_a; phase["finalize"] += t_c - t_b
         phase["export+gather"] += t_d - t_c; phase["d2h"] += t_e - t_d
+        step_log.append((round((t_b - t_a) * 1e3, 3), round((t_c - t_b) * 1e3, 3), round((t_d - t_c) * 1e3, 3)))
 
     def barrier():
         if world > 1:
@@ -255,6 +257,11 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.sync()
+    # (the annotation and the read simulator leave millions of Python objects behind: a generation-2 collection of the
+    #  cyclic garbage collector inside the timed loop costs 4 ms, most of a step)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     for k in phase:
         phase[k] = 0.0
@@ -269,6 +276,8 @@ def main():
     eng.sync()          # the last sample's tables are in host memory
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    log("rank %d host ms per step (reset+submit, finalize, export): %s" % (rank, step_log[-args.steps:]))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
