@@ -329,7 +329,7 @@ def main():
     knames = {"count_ms": ["count_kernel"], "scan_ms": ["scan_tiles_kernel", "reduce_tiles_kernel"],
               "stats_ms": ["intron_stats_kernel<256", "intron_stats_kernel<64"]}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
         if world == 1 and args.genome == "grch38" and args.pairs == 50_000_000 and not args.stranded and args.order == "sorted":
             traffic = sum(pmc["kernels"][k]["hbm_bytes_corrected"] for k in knames[dom])
     except Exception:

@@ -389,8 +389,11 @@ int irf_cigar2block(const uint32_t* cigar, uint32_t n_cigar,
  * assembled on the device.  The result of a feed is a DEVICE-resident
  * irf_batch — equal, column by column, to what irf_reader_* yields for the
  * same bytes — that goes straight into irf_submit_batch of a context on the
- * same device.  params.mate_join must be 0 (upstream's pairing: the next record
- * is the mate); the BAM header must be complete before the first batch appears.
+ * same device.  params.mate_join = 0: upstream's pairing, the next record is the
+ * mate (name-collated input; the fragments then arrive in no coordinate order:
+ * see irf_set_input_order); 1: coordinate-sorted input, mates are joined by read
+ * name on the device (records whose mate has not arrived wait for the next feed).
+ * The BAM header must be complete before the first batch appears.
  * The batch of a feed stays valid until the next-but-one feed (two slots): call
  * irf_sync on the consuming context before feeding twice more.                */
 typedef struct irf_dreader irf_dreader;
