@@ -40,8 +40,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=50_000_000, help="pairs per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--stranded", type=int, default=0)
@@ -328,15 +328,24 @@ def main():
     traffic = None
     knames = {"count_ms": ["count_kernel"], "scan_ms": ["scan_tiles_kernel", "reduce_tiles_kernel"],
               "stats_ms": ["intron_stats_kernel<256", "intron_stats_kernel<64"]}
+    traffic_note = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
         if world == 1 and args.genome == "grch38" and args.pairs == 50_000_000 and not args.stranded and args.order == "sorted":
-            traffic = sum(pmc["kernels"][k]["hbm_bytes_corrected"] for k in knames[dom])
+            # the counters were collected on a particular version of the kernels: a later change of their sources makes the
+            # committed figure stale, and the line then says so instead of repeating it
+            import hashlib
+            cur = {f: hashlib.sha256(open(os.path.join(ROOT, "irfinder_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in ("count.hip", "stats.hip", "kernels.h")}
+            if pmc.get("sources_sha256") == cur:
+                traffic = sum(pmc["kernels"][k]["hbm_bytes_corrected"] for k in knames[dom])
+                traffic_note = "profiles/r03_pmc_summary.json (tools/pmc_traffic.sh on these kernel sources)"
+            else:
+                traffic_note = "profiles/r03_pmc_summary.json was collected on other kernel sources: run tools/pmc_traffic.sh again"
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "scan_tiles_kernel", "stats_ms": "intron_stats_kernel"}[dom],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "per_kernel": kernels, "layout": lay}
+                "traffic": traffic, "traffic_source": traffic_note, "per_kernel": kernels, "layout": lay}
 
     # ---------------- CPU baseline (oracle, bounded sample, 1 core) ----------------
     cpu = None

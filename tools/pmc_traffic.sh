@@ -8,7 +8,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 280 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench --no-random-leg > $out/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/$c.log; exit 1; }
 done
 python3 - $out <<'P'
-import csv, glob, json, sys, collections, re
+import csv, glob, json, sys, collections, re, hashlib, os
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -19,6 +19,7 @@ for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True
 out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench --no-random-leg (two separate passes)",
        "unit": "bytes per launch (mean over launches)",
        "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section; factor 2.0 calibrated in r01b on a kernel that read exactly 2*plane_positions*4 B)",
+       "sources_sha256": {f: hashlib.sha256(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "irfinder_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in ("count.hip", "stats.hip", "kernels.h")},
        "kernels": {}}
 for k, d in sorted(vals.items()):
     f = d.get('FETCH_SIZE', []); w = d.get('WRITE_SIZE', [])
