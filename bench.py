@@ -198,14 +198,8 @@ def main():
             slot = out["slots"][out["n_step"] & 1]
             out["n_step"] += 1
             tabs = {}
-            eng.export_device(COL_IR_NONDIR_F64 | COL_NO_SYNC, slot["ir_f64"].data_ptr())
-            eng.export_device(COL_IR_NONDIR_U32 | COL_NO_SYNC, slot["ir_u32"].data_ptr())
-            tabs["ir_f64"], tabs["ir_u32"] = slot["ir_f64"], slot["ir_u32"]
-            if eng.export_size(COL_IR_DIR_F64):
-                eng.export_device(COL_IR_DIR_F64 | COL_NO_SYNC, slot["ir_dir_f64"].data_ptr())
-                eng.export_device(COL_IR_DIR_U32 | COL_NO_SYNC, slot["ir_dir_u32"].data_ptr())
-                tabs["ir_dir_f64"], tabs["ir_dir_u32"] = slot["ir_dir_f64"], slot["ir_dir_u32"]
-            # (the small tables after the IR tables: their copies stay on the main stream, in front of the next irf_reset)
+            # (the small tables first: their copies stay on the main stream, in front of the next irf_reset, and are done
+            #  before the copy kernels of the IR tables fill the device)
             for key, col, dt in (("sp_cnt", COL_SP_CNT, torch.int32), ("roi_cnt", COL_ROI_CNT, torch.int32), ("chr_cnt", COL_CHR_CNT, torch.int32),
                                  ("known_cnt", COL_KNOWN_CNT, torch.int32), ("junc_keys", COL_JUNC_KEYS, torch.int64), ("junc_counts", COL_JUNC_COUNTS, torch.int32)):
                 n = eng.export_size(col)
@@ -215,6 +209,13 @@ def main():
                 if n:
                     eng.export_device(col | COL_NO_SYNC, t.data_ptr())
                 tabs[key] = t
+            eng.export_device(COL_IR_NONDIR_F64 | COL_NO_SYNC, slot["ir_f64"].data_ptr())
+            eng.export_device(COL_IR_NONDIR_U32 | COL_NO_SYNC, slot["ir_u32"].data_ptr())
+            tabs["ir_f64"], tabs["ir_u32"] = slot["ir_f64"], slot["ir_u32"]
+            if eng.export_size(COL_IR_DIR_F64):
+                eng.export_device(COL_IR_DIR_F64 | COL_NO_SYNC, slot["ir_dir_f64"].data_ptr())
+                eng.export_device(COL_IR_DIR_U32 | COL_NO_SYNC, slot["ir_dir_u32"].data_ptr())
+                tabs["ir_dir_f64"], tabs["ir_dir_u32"] = slot["ir_dir_f64"], slot["ir_dir_u32"]
             out["got"] = irfdist.gather_tables(tabs, None)
             t_d = time.perf_counter()
         else:

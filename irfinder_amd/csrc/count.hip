@@ -755,15 +755,15 @@ __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T
 __global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* __restrict__ planes, uint8_t* dirty, uint64_t plane_stride, uint64_t n_groups) {
     typedef uint32_t V4 __attribute__((ext_vector_type(4)));
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t g0 = (((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6) << 6;      // the wave's first group
-    if (g0 >= n_groups) return;
+    const uint32_t q = lane >> 4, sh = ((lane >> 2) & 3u) * 8u;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t g0 = wave0 << 6; g0 < n_groups; g0 += n_waves << 6) {       // the wave's next 64 groups
     const uint64_t g = g0 + lane;
     uint4 m = make_uint4(0u, 0u, 0u, 0u);
     if (g < n_groups) m = reinterpret_cast<const uint4*>(dirty)[g];
     const bool any = (m.x | m.y | m.z | m.w) != 0u;
     uint64_t todo = __ballot(any);
     if (any) reinterpret_cast<uint4*>(dirty)[g] = make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t q = lane >> 4, sh = ((lane >> 2) & 3u) * 8u;
     while (todo) {
         const int s = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
@@ -775,6 +775,7 @@ __global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* __restrict__
             const uint64_t line = mark >> 1, dir = mark & 1u;
             *reinterpret_cast<V4*>(planes + dir * plane_stride + line * 16u + (lane & 3u) * 4u) = V4{0u, 0u, 0u, 0u};
         }
+    }
     }
 }
 
@@ -788,9 +789,10 @@ void launch_known_junction_depth(const CountTables& T, hipStream_t s) {
 void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride, hipStream_t s) {
     const uint64_t n_groups = dirty_map_bytes(plane_stride) / 16u;
     if (!n_groups) return;
-    // (short-lived workgroups, 4096 marks each: the clear runs on a stream of the lowest priority next to the table
-    //  export's copy kernels, which take the slots as they come free)
-    hipLaunchKernelGGL(sparse_clear_kernel, dim3((uint32_t)((n_groups + 255u) / 256u)), dim3(256), 0, s, planes, dirty, plane_stride, n_groups);
+    // (two workgroups per CU, looping: the clear is not on the critical path — the next sample takes the OTHER spare set —
+    //  and must leave room for the copy kernels of the table export and for the next count kernel, which start next to it)
+    const uint64_t wgs = (n_groups + 255u) / 256u;
+    hipLaunchKernelGGL(sparse_clear_kernel, dim3((uint32_t)(wgs < 512u ? wgs : 512u)), dim3(256), 0, s, planes, dirty, plane_stride, n_groups);
 }
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {

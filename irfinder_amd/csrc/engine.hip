@@ -47,9 +47,11 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;      // elements
+    bool owned = true;   // false: a view into another buffer (irf_ctx: the counter pool)
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
-    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; cap = 0; owned = true; }
+    void view(void* base, size_t n) { release(); p = static_cast<T*>(base); cap = n; owned = false; }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(owned, o.owned); }
     // grows (never shrinks); contents are NOT preserved
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
@@ -114,12 +116,25 @@ struct irf_ctx {
     DevBuf<uint32_t> ro_idx_a, ro_idx_b, ro_nblk, ro_chr, ro_start, ro_end, ro_off, ro_bs, ro_bl;
     DevBuf<uint8_t> ro_flags, ro_rd;
     int reorder(dev::BatchDev& B);
-    DevBuf<uint8_t> d_dirty, d_dirty_alt;        // which 64-byte lines of d_diff / d_diff_alt hold something (kernels.h: CountTables.dirty)
-    DevBuf<int32_t> d_diff_alt;
-    DevBuf<uint32_t> d_seg_sum_alt;
+    DevBuf<uint8_t> d_dirty;                     // which 64-byte lines of d_diff hold something (kernels.h: CountTables.dirty)
+    // Spare plane sets for the following samples.  A set that irf_reset swapped out is dirty (its line marks say where) and is
+    // cleared on the side stream behind the statistics kernels of the sample that follows; with TWO spare sets the next
+    // sample takes the one cleared a whole sample ago and never waits for the clear that was just queued (which then
+    // runs next to the table export and the start of the next count kernel).  The second set is allocated with the first
+    // one (behind the first sample's statistics) if the device has plenty of room for it.
+    struct PlaneSet {
+        DevBuf<int32_t> diff;
+        DevBuf<uint32_t> seg_sum;
+        DevBuf<uint8_t> dirty;
+        hipEvent_t cleared = nullptr;
+        bool clean = false;                      // a clear is queued (or done): `cleared` says when
+        uint64_t seq = 0;                        // order in which the clears were queued
+        bool allocated(uint64_t stride) const { return stride && diff.cap >= 2 * stride && seg_sum.cap >= 2 * stride / dev::kDepthSegment && dirty.cap >= dev::dirty_map_bytes(stride); }
+        void release() { diff.release(); seg_sum.release(); dirty.release(); clean = false; }
+    } spare[2];
+    uint64_t clear_seq = 0;
     hipStream_t clear_stream = nullptr;
-    hipEvent_t ev_stats_done = nullptr, ev_cleared = nullptr;
-    bool alt_clean = false;                      // d_*_alt are (being) cleared: ev_cleared says when
+    hipEvent_t ev_stats_done = nullptr;
     DevBuf<uint32_t> d_carry;                    // [2][plane_stride/256] depth before each segment (after finalize)
     DevBuf<uint64_t> d_chr_base;
     DevBuf<uint32_t> d_chr_len;
@@ -137,6 +152,8 @@ struct irf_ctx {
     DevBuf<uint32_t> d_wex;                       // exclusive scan of the sorted weights
     DevBuf<unsigned long long> d_scalars;        // [0] junc_count, [1] key OR, [2] key AND, [3],[4] dir votes
     DevBuf<uint32_t> d_err;
+    DevBuf<uint8_t> d_counter_pool;              // d_scalars, d_err, d_chr_cnt, d_roi_cnt, d_sp_cnt, d_known_cnt are views into it
+    size_t counter_pool_bytes = 0;
     DevBuf<uint32_t> d_ws;                       // workspace of the carry scan
     DevBuf<uint32_t> d_ws_sort;                  // workspace of the junction radix sort / compaction
     DevBuf<uint32_t> d_flags, d_uidx, d_ustart, d_ucount;
@@ -275,7 +292,7 @@ int irf_ctx::init() {
         HIP_TRY(hipEventCreateWithFlags(&ev_export_done, hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&ev_stats_done, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_cleared, hipEventDisableTiming));
+    for (auto& sp : spare) HIP_TRY(hipEventCreateWithFlags(&sp.cleared, hipEventDisableTiming));
     for (auto& s : stage) {
         HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
@@ -295,7 +312,7 @@ void irf_ctx::free_events() {
     for (auto& p : count_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     count_events.clear();
     if (ev_stats_done) { (void)hipEventDestroy(ev_stats_done); ev_stats_done = nullptr; }
-    if (ev_cleared) { (void)hipEventDestroy(ev_cleared); ev_cleared = nullptr; }
+    for (auto& sp : spare) if (sp.cleared) { (void)hipEventDestroy(sp.cleared); sp.cleared = nullptr; }
     if (clear_stream) { (void)hipStreamDestroy(clear_stream); clear_stream = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
@@ -385,13 +402,11 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     TRY(upload(this, d_chr_owned, chr_owned));
     {
         if (clear_stream) HIP_TRY(hipStreamSynchronize(clear_stream));
-        d_diff_alt.release(); d_seg_sum_alt.release(); d_dirty_alt.release();      // (a new map: the spare planes are allocated again when first needed)
-        alt_clean = false;
+        for (auto& sp : spare) sp.release();      // (a new map: the spare planes are allocated again when first needed)
         hipError_t e = d_diff.reserve(2 * plane_stride);
         if (e == hipSuccess) e = d_dirty.reserve(dev::dirty_map_bytes(plane_stride));
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the depth planes failed");
     }
-    TRY(alloc_zero(this, d_chr_cnt, (size_t)n * 2));
     {
         const uint64_t n_seg = 2 * plane_stride / dev::kDepthSegment;
         hipError_t e = d_carry.reserve(n_seg);
@@ -431,7 +446,6 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         TRY(upload(this, d_roi_gend, ge));
         TRY(upload(this, d_roi_idx, fi));
         TRY(upload(this, d_roi_bucket, bucket));
-        TRY(alloc_zero(this, d_roi_cnt, (size_t)n_roi * 2));
     }
     // ---- SpansPoint: (slot,pos)-sorted; reference-only chromosomes at the tail ----
     n_sp = (uint32_t)ref.sp_pos.size();
@@ -469,7 +483,6 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         }
         TRY(upload(this, d_sp_row, row));
         sp_bucket_h.swap(bucket);
-        TRY(alloc_zero(this, d_sp_cnt, (size_t)n_sp * 2));
     }
     // ---- known junctions sorted by (slot,left,right) ----
     {
@@ -524,7 +537,6 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         TRY(upload(this, d_known_keys, kkeys));
         TRY(upload(this, d_known_dir, kdir));
         TRY(upload(this, d_known_kjidx, krow));
-        TRY(alloc_zero(this, d_known_cnt, (size_t)n_kj * 2));
     }
     // ---- introns ----
     {
@@ -669,8 +681,19 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         sharded = false;
         for (uint32_t i = 0; i < n; i++) if (!chr_owned[i]) sharded = true;
     }
-    TRY(alloc_zero(this, d_scalars, 8));
-    TRY(alloc_zero(this, d_err, 1));
+    {
+        // every counter irf_reset zeroes (except the planes) in ONE allocation: one memset per sample instead of six
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_scal = take(8 * sizeof(unsigned long long)), o_err = take(sizeof(uint32_t)), o_chr = take((size_t)n_chr * 2 * 4),
+                     o_roi = take((size_t)n_roi * 2 * 4), o_sp = take((size_t)n_sp * 2 * 4), o_kj = take((size_t)n_kj * 2 * 4);
+        d_scalars.release(); d_err.release(); d_chr_cnt.release(); d_roi_cnt.release(); d_sp_cnt.release(); d_known_cnt.release();
+        if (d_counter_pool.reserve(off) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the counter tables failed");
+        counter_pool_bytes = off;
+        uint8_t* base = d_counter_pool.p;
+        d_scalars.view(base + o_scal, 8); d_err.view(base + o_err, 1); d_chr_cnt.view(base + o_chr, (size_t)n_chr * 2);
+        d_roi_cnt.view(base + o_roi, (size_t)n_roi * 2); d_sp_cnt.view(base + o_sp, (size_t)n_sp * 2); d_known_cnt.view(base + o_kj, (size_t)n_kj * 2);
+    }
     {
         uint64_t cap = std::max<uint64_t>(P.junc_event_capacity, 1024);
         hipError_t e = d_junc_a.reserve(cap);
@@ -683,27 +706,23 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
 
 int irf_ctx::zero_counters() {
     HIP_TRY(hipSetDevice(device));
-    // (clearing a second set of planes on a side stream was tried twice: under the next sample's count kernel that kernel
-    //  slows down by exactly the time of the memset, under the statistics kernels they slow down by MORE than that
-    //  (1.85 -> 3.13 ms) — both are latency-bound and lose to a bandwidth-bound neighbour; the planes are cleared in line)
-    if (alt_clean && d_diff_alt.cap >= 2 * plane_stride && d_seg_sum_alt.cap >= 2 * plane_stride / dev::kDepthSegment) {
-        // the spare planes were cleared behind the last sample's statistics: take them
-        d_diff.swap(d_diff_alt);
-        d_seg_sum.swap(d_seg_sum_alt);
-        d_dirty.swap(d_dirty_alt);
-        HIP_TRY(hipStreamWaitEvent(stream, ev_cleared, 0));
-        alt_clean = false;
+    // (a spare set of planes, cleared behind an earlier sample's statistics kernels, is swapped in; without one the planes
+    //  are cleared in line)
+    PlaneSet* take = nullptr;        // the spare set whose clear was queued first
+    for (auto& sp : spare) if (sp.clean && sp.allocated(plane_stride) && (!take || sp.seq < take->seq)) take = &sp;
+    if (take) {
+        HIP_TRY(hipStreamWaitEvent(stream, take->cleared, 0));
+        d_diff.swap(take->diff);
+        d_seg_sum.swap(take->seg_sum);
+        d_dirty.swap(take->dirty);
+        take->clean = false;         // (it now holds the planes of the sample that just ended: dirty, marks valid)
     } else {
         if (plane_stride) HIP_TRY(hipMemsetAsync(d_diff.p, 0, 2 * plane_stride * sizeof(int32_t), stream));
         if (plane_stride) HIP_TRY(hipMemsetAsync(d_seg_sum.p, 0, 2 * plane_stride / dev::kDepthSegment * sizeof(uint32_t), stream));
         if (plane_stride) HIP_TRY(hipMemsetAsync(d_dirty.p, 0, dev::dirty_map_bytes(plane_stride), stream));
     }
-    if (n_chr) HIP_TRY(hipMemsetAsync(d_chr_cnt.p, 0, (size_t)n_chr * 2 * sizeof(uint32_t), stream));
-    if (n_roi) HIP_TRY(hipMemsetAsync(d_roi_cnt.p, 0, (size_t)n_roi * 2 * sizeof(uint32_t), stream));
-    if (n_sp) HIP_TRY(hipMemsetAsync(d_sp_cnt.p, 0, (size_t)n_sp * 2 * sizeof(uint32_t), stream));
-    if (n_kj) HIP_TRY(hipMemsetAsync(d_known_cnt.p, 0, (size_t)n_kj * 2 * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(d_scalars.p, 0, 8 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), stream));
+    // chromosome / ROI / SpansPoint / known-junction counters, the scalars and the error flags: one pool
+    HIP_TRY(hipMemsetAsync(d_counter_pool.p, 0, counter_pool_bytes, stream));
     n_fragments = n_blocks = junc_upper = 0;
     n_unique = n_events = 0;
     finalized = results_ready = false;
@@ -1047,30 +1066,45 @@ int irf_ctx::finalize() {
     else dev::launch_ir_rows(intron_tables(0, 0, false), stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], stream));
-    if (plane_stride && !alt_clean) {
-        // the next sample's planes: cleared on the side stream as soon as the statistics kernels have finished (a memset
-        // UNDER them costs them more than its own time; behind them the device is idle while the host fetches the tables)
+    if (plane_stride) {
+        // the following samples' planes: cleared on the side stream as soon as the statistics kernels have finished (a
+        // memset UNDER them costs them more than its own time)
         const size_t n_seg2 = 2 * plane_stride / dev::kDepthSegment;
-        const bool had_spare = d_diff_alt.cap >= 2 * plane_stride && d_dirty_alt.cap >= dev::dirty_map_bytes(plane_stride);
-        if (d_diff_alt.reserve(2 * plane_stride) == hipSuccess && d_seg_sum_alt.reserve(n_seg2) == hipSuccess &&
-            d_dirty_alt.reserve(dev::dirty_map_bytes(plane_stride)) == hipSuccess) {
-            HIP_TRY(hipEventRecord(ev_stats_done, stream));
-            HIP_TRY(hipStreamWaitEvent(clear_stream, ev_stats_done, 0));
-            if (had_spare) {
-                // the spare planes were this context's planes one sample ago: only the lines that sample marked hold anything
-                // (a third of them at 50 M pairs)
-                dev::launch_sparse_clear(d_diff_alt.p, d_dirty_alt.p, plane_stride, clear_stream);
+        bool waited = false;
+        for (int k = 0; k < 2; k++) {
+            PlaneSet& sp = spare[k];
+            if (sp.clean) continue;
+            const bool had = sp.allocated(plane_stride);
+            // a first spare set at once; the second one with it when the device has plenty of room (three more sets would
+            // still fit), else never
+            if (!had && k == 1) {
+                size_t free_b = 0, total_b = 0;
+                const size_t set_b = (size_t)2 * plane_stride * sizeof(int32_t);
+                if (!spare[0].allocated(plane_stride) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * set_b) { (void)hipGetLastError(); continue; }
+            }
+            if (sp.diff.reserve(2 * plane_stride) != hipSuccess || sp.seg_sum.reserve(n_seg2) != hipSuccess ||
+                sp.dirty.reserve(dev::dirty_map_bytes(plane_stride)) != hipSuccess) {
+                (void)hipGetLastError();           // no room: without a spare set irf_reset clears the planes in line
+                sp.release();
+                continue;
+            }
+            if (!waited) {
+                HIP_TRY(hipEventRecord(ev_stats_done, stream));
+                HIP_TRY(hipStreamWaitEvent(clear_stream, ev_stats_done, 0));
+                waited = true;
+            }
+            if (had) {
+                // this set held a sample's planes: only the lines that sample marked hold anything (a fifth of them at 50 M pairs)
+                dev::launch_sparse_clear(sp.diff.p, sp.dirty.p, plane_stride, clear_stream);
                 HIP_TRY(hipGetLastError());
             } else {
-                HIP_TRY(hipMemsetAsync(d_diff_alt.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
-                HIP_TRY(hipMemsetAsync(d_dirty_alt.p, 0, dev::dirty_map_bytes(plane_stride), clear_stream));
+                HIP_TRY(hipMemsetAsync(sp.diff.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
+                HIP_TRY(hipMemsetAsync(sp.dirty.p, 0, dev::dirty_map_bytes(plane_stride), clear_stream));
             }
-            HIP_TRY(hipMemsetAsync(d_seg_sum_alt.p, 0, n_seg2 * sizeof(uint32_t), clear_stream));
-            HIP_TRY(hipEventRecord(ev_cleared, clear_stream));
-            alt_clean = true;
-        } else {
-            (void)hipGetLastError();           // no room for a second set: the planes are cleared in line, as before
-            d_diff_alt.release(); d_seg_sum_alt.release(); d_dirty_alt.release();
+            HIP_TRY(hipMemsetAsync(sp.seg_sum.p, 0, n_seg2 * sizeof(uint32_t), clear_stream));
+            HIP_TRY(hipEventRecord(sp.cleared, clear_stream));
+            sp.clean = true;
+            sp.seq = ++clear_seq;
         }
     }
     HIP_TRY(hipStreamSynchronize(stream));
