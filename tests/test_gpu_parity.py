@@ -320,6 +320,36 @@ def test_queued_table_exports_overlap_the_next_sample():
         assert (f64[1] > 0).sum() > 3, k
 
 
+@pytest.mark.parametrize("keep_depth", [0, 1])
+def test_many_samples_through_one_context_leave_nothing_behind(keep_depth):
+    """Six samples through one context: sorted and shuffled batches (shuffled ones are counted as given: every difference
+    event then takes the far path — line cache, fallback atomics), small and large, one of them empty, then the first one
+    again.  Every sample's tables equal the oracle's for that sample alone: the planes a sample inherits (two spare sets,
+    cleared by the line marks of the sample that used them: engine.hip PlaneSet, count.hip sparse_clear_kernel) hold
+    nothing of its predecessors.  keep_depth = 1: whole-genome planes, no plane map."""
+    ann, sim = small_world(seed=8)
+    names, lens, _ = read_batch(sim.bam(0, 100))
+    rng = np.random.default_rng(11)
+    spans = [(0, 25000), (25000, 4000), (30000, 15000), None, (0, 25000), (45000, 9000)]
+    ref = engine.RefTables.from_texts(ann.ref_texts())
+    e = engine.Engine(ref, engine.default_params(keep_depth=keep_depth))
+    e.chr_map_update(names, lens)
+    for k, sp in enumerate(spans):
+        if sp is None:
+            batches = []
+        else:
+            b = read_batch(sim.bam(*sp))[2]
+            if k % 2 == 1 or k == 4:
+                b = b.select(rng.permutation(b.n_frag))          # (counted in this order: IRF_ORDER_SORTED is only a hint)
+            batches = split(b, 2)
+        e.reset()
+        for b in batches:
+            e.process(b)
+        e.finalize()
+        o, c = run_orc(ann.ref_texts(), names, lens, batches, keep_depth=keep_depth)
+        assert_results_equal(e.results(), c, rel=0.0, what="sample %d" % k)
+
+
 def test_diagnostic_environment_switches_do_not_reach_the_product(monkeypatch):
     """IRF_ABLATE / IRF_ABLATE_STATS / IRF_RESCAN_PLANES / IRF_STATS_* exist only in -DIRF_DIAG builds
     (tools/build_variant.sh): with them set, the shipped library still gives the oracle's tables."""
