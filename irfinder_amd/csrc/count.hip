@@ -643,7 +643,9 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                 if (v1 && !(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + T.plane_stride + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 S.lcnt[slot][cell] = 0;
             }
-            const int32_t s0 = row_sum_dpp(v0), s1 = row_sum_dpp(v1);
+            // (the two strands' sums in one pass: the packed halves of a sum cannot overflow while use_win holds, see far_event)
+            const int32_t sp = row_sum_dpp(v);
+            const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
             if (cell == 15u && s0) seg_add(T, 0u, c, s0);
             if (cell == 15u && s1) seg_add(T, 1u, c, s1);
             // (a claimed line is marked for both strands whatever it holds: marking too much only costs the clear a line)
@@ -661,7 +663,8 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
                 S.tile[e] = 0;
             }
             // the window starts on a multiple of 64: a wave's 64 positions share one segment
-            const int32_t s0 = wave_sum_dpp(v0), s1 = wave_sum_dpp(v1);
+            const int32_t sp = wave_sum_dpp(v);
+            const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
             if (lane == 63u) {
                 if (s0) seg_add(T, 0u, win + e, s0);
                 if (s1) seg_add(T, 1u, win + e, s1);
