@@ -16,64 +16,94 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__global__ __launch_bounds__(kThreads) void reorder_keys_kernel(const uint32_t* __restrict__ chr, const uint32_t* __restrict__ start,
-                                                                const uint64_t* __restrict__ chr_base, uint32_t n_chr, uint32_t n,
-                                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+// A scattered 4-byte read costs a whole 64-byte sector.  The two gathers therefore read array-of-structs copies that two
+// coalesced passes build first: one 32-byte record per fragment (the four columns, its first block, its block count, with
+// the CSR check of a device-resident batch: neighbours are adjacent here) and one 8-byte record per block.
+struct __attribute__((aligned(32))) FragRec { uint32_t chr, start, end, off0, nblk, flags, pad0, pad1; };
+constexpr uint32_t kReadShift = 30;          // BlkRec8.y = len | read << 30
+
+__global__ __launch_bounds__(kThreads) void reorder_keys_kernel(BatchDev B, const uint64_t* __restrict__ chr_base, uint32_t n_chr,
+                                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, FragRec* __restrict__ recs,
+                                                                uint32_t* err_flags) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = chr[i];
-    keys[i] = c < n_chr ? (chr_base[c] + start[i]) >> kReorderShift : 0ull;      // (a bad id is reported by the count kernel)
+    if (i >= B.n_frag) return;
+    const uint32_t c = B.frag_chr[i], st = B.frag_start[i];
+    keys[i] = c < n_chr ? (chr_base[c] + st) >> kReorderShift : 0ull;      // (a bad id is reported by the count kernel)
     idx[i] = i;
-}
-
-// fragment columns in the new order + the block count of every fragment.  The CSR offsets of a device-resident batch are
-// checked here as the count kernel checks them in sorted mode (ERR_CSR: not non-decreasing, beyond n_blk, not spanning
-// [0, n_blk]); a fragment with bad offsets gets no blocks, so nothing is read out of bounds.
-__global__ __launch_bounds__(kThreads) void reorder_frags_kernel(BatchDev B, const uint32_t* __restrict__ perm, uint32_t* __restrict__ chr,
-                                                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ start,
-                                                                 uint32_t* __restrict__ end, uint32_t* __restrict__ nblk, uint32_t* err_flags) {
-    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
-    if (j > B.n_frag) return;
-    if (j == B.n_frag) { nblk[j] = 0u; return; }           // (the scan's last element: the total lands behind it)
-    const uint32_t i = perm[j];
     const uint32_t o0 = B.frag_blk_off[i], o1 = B.frag_blk_off[i + 1u];
-    chr[j] = B.frag_chr[i];
-    flags[j] = B.frag_flags[i];
-    start[j] = B.frag_start[i];
-    end[j] = B.frag_end[i];
+    // ERR_CSR as the count kernel reports it in sorted mode: not non-decreasing, beyond n_blk, not spanning [0, n_blk];
+    // a fragment with bad offsets gets no blocks, so nothing is read out of bounds
     const bool ok = o0 <= o1 && o1 <= B.n_blk;
-    nblk[j] = ok ? o1 - o0 : 0u;
     if (!ok || (i == 0u && o0 != 0u) || (i == B.n_frag - 1u && o1 != B.n_blk)) atomicOr(err_flags, (uint32_t)ERR_CSR);
+    FragRec r;
+    r.chr = c; r.start = st; r.end = B.frag_end[i]; r.off0 = o0; r.nblk = ok ? o1 - o0 : 0u; r.flags = B.frag_flags[i]; r.pad0 = 0u; r.pad1 = 0u;
+    recs[i] = r;
 }
 
-// the blocks of fragment perm[j] move to new_off[j]; four lanes per fragment (fragments have a handful of blocks)
-__global__ __launch_bounds__(kThreads) void reorder_blocks_kernel(BatchDev B, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ new_off,
-                                                                  uint32_t* __restrict__ bs, uint32_t* __restrict__ bl, uint8_t* __restrict__ rd) {
+__global__ __launch_bounds__(kThreads) void reorder_pack_blocks_kernel(BatchDev B, uint2* __restrict__ pk, uint32_t* err_flags) {
+    const uint32_t b = blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B.n_blk) return;
+    const uint32_t len = B.blk_len[b], rd = B.blk_read[b];
+    // (a block of 2^30 bases or a read index above 3 cannot be valid input: reported like a block beyond its chromosome)
+    if (len >= (1u << kReadShift) || rd > 3u) atomicOr(err_flags, (uint32_t)ERR_BLOCK_RANGE);
+    pk[b] = make_uint2(B.blk_start[b], (len & ((1u << kReadShift) - 1u)) | (rd << kReadShift));
+}
+
+// fragment columns in the new order, the block count of every fragment and where its blocks lie in the old order
+__global__ __launch_bounds__(kThreads) void reorder_frags_kernel(uint32_t n_frag, const FragRec* __restrict__ recs, const uint32_t* __restrict__ perm,
+                                                                 uint32_t* __restrict__ chr, uint8_t* __restrict__ flags, uint32_t* __restrict__ start,
+                                                                 uint32_t* __restrict__ end, uint32_t* __restrict__ nblk, uint32_t* __restrict__ src_off) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j > n_frag) return;
+    if (j == n_frag) { nblk[j] = 0u; return; }           // (the scan's last element: the total lands behind it)
+    const FragRec r = recs[perm[j]];
+    chr[j] = r.chr;
+    flags[j] = (uint8_t)r.flags;
+    start[j] = r.start;
+    end[j] = r.end;
+    nblk[j] = r.nblk;
+    src_off[j] = r.off0;
+}
+
+// the blocks of the fragment now at j move to new_off[j]; four lanes per fragment (fragments have a handful of blocks)
+__global__ __launch_bounds__(kThreads) void reorder_blocks_kernel(uint32_t n_frag, const uint2* __restrict__ pk, const uint32_t* __restrict__ src_off,
+                                                                  const uint32_t* __restrict__ new_off, uint32_t* __restrict__ bs,
+                                                                  uint32_t* __restrict__ bl, uint8_t* __restrict__ rd) {
     const uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     const uint64_t j = t >> 2;
-    if (j >= B.n_frag) return;
-    const uint32_t src = B.frag_blk_off[perm[j]];
+    if (j >= n_frag) return;
+    const uint32_t src = src_off[j];
     const uint32_t dst = new_off[j], cnt = new_off[j + 1u] - dst;
     for (uint32_t k = (uint32_t)(t & 3u); k < cnt; k += 4u) {
-        bs[dst + k] = B.blk_start[src + k];
-        bl[dst + k] = B.blk_len[src + k];
-        rd[dst + k] = B.blk_read[src + k];
+        const uint2 v = pk[src + k];
+        bs[dst + k] = v.x;
+        bl[dst + k] = v.y & ((1u << kReadShift) - 1u);
+        rd[dst + k] = (uint8_t)(v.y >> kReadShift);
     }
 }
 
 }   // namespace
 
-void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, uint32_t* idx, hipStream_t s) {
-    hipLaunchKernelGGL(reorder_keys_kernel, dim3((B.n_frag + kThreads - 1) / kThreads), dim3(kThreads), 0, s, B.frag_chr, B.frag_start, chr_base, n_chr, B.n_frag, keys, idx);
+size_t reorder_frag_rec_bytes() { return sizeof(FragRec); }
+
+void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, uint32_t* idx, void* frag_recs, void* blk_recs,
+                         uint32_t* err_flags, hipStream_t s) {
+    hipLaunchKernelGGL(reorder_keys_kernel, dim3((B.n_frag + kThreads - 1) / kThreads), dim3(kThreads), 0, s, B, chr_base, n_chr, keys, idx,
+                       static_cast<FragRec*>(frag_recs), err_flags);
+    if (B.n_blk) hipLaunchKernelGGL(reorder_pack_blocks_kernel, dim3((B.n_blk + kThreads - 1) / kThreads), dim3(kThreads), 0, s, B, static_cast<uint2*>(blk_recs), err_flags);
 }
 
-void launch_reorder_frags(const BatchDev& B, const uint32_t* perm, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end, uint32_t* nblk, uint32_t* err_flags, hipStream_t s) {
-    hipLaunchKernelGGL(reorder_frags_kernel, dim3(B.n_frag / kThreads + 1u), dim3(kThreads), 0, s, B, perm, chr, flags, start, end, nblk, err_flags);
+void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint32_t* perm, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
+                          uint32_t* nblk, uint32_t* src_off, hipStream_t s) {
+    hipLaunchKernelGGL(reorder_frags_kernel, dim3(n_frag / kThreads + 1u), dim3(kThreads), 0, s, n_frag, static_cast<const FragRec*>(frag_recs), perm, chr, flags,
+                       start, end, nblk, src_off);
 }
 
-void launch_reorder_blocks(const BatchDev& B, const uint32_t* perm, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd, hipStream_t s) {
-    const uint64_t threads = (uint64_t)B.n_frag * 4u;
-    hipLaunchKernelGGL(reorder_blocks_kernel, dim3((uint32_t)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, B, perm, new_off, bs, bl, rd);
+void launch_reorder_blocks(uint32_t n_frag, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
+                           hipStream_t s) {
+    const uint64_t threads = (uint64_t)n_frag * 4u;
+    hipLaunchKernelGGL(reorder_blocks_kernel, dim3((uint32_t)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, n_frag,
+                       static_cast<const uint2*>(blk_recs), src_off, new_off, bs, bl, rd);
 }
 
 }   // namespace dev

@@ -51,6 +51,9 @@ static int run_device_reader(const std::vector<const char*>& pos, const irf_para
     int rc = irf_create(&P, ref, device, &ctx);
     irf_ref_free(ref);
     if (rc != 0) return die("irf_create", "no HIP device or bad parameters");
+    // without --sorted the file is name-collated: its fragments arrive in no coordinate order, and the engine bins every
+    // batch by coordinate before it counts it (same tables, a third of the count time)
+    if (!P.mate_join && irf_set_input_order(ctx, IRF_ORDER_ANY) != 0) return die("irf_set_input_order", irf_last_error(ctx));
     irf_dreader* dr = nullptr;
     if (irf_dreader_create(&P, device, &dr) != 0) return die("irf_dreader_create", "no HIP device or bad parameters");
     // pipelined: while a piece is copied and inflated, the fragments of the piece before it are assembled and counted,
