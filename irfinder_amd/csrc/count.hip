@@ -716,40 +716,43 @@ __global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables 
 // The kernel also takes the strandedness vote (JunctionCount::Directional, OQ-5: known junctions only): irf_finalize
 // needs it before it can start the statistics kernels, and this is the first pass over the junction counters.
 __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool in = i < T.n_known;
-    const uint32_t ii = in ? i : 0u;
-    const uint32_t row = T.known_kjidx[ii];
-    int cnt[2];
-    cnt[0] = in ? (int)T.known_cnt[row] : 0;
-    cnt[1] = in ? (int)T.known_cnt[(uint64_t)T.n_kj + row] : 0;
-    {
-        unsigned long long same = 0, opp = 0;
-        const uint32_t kd = T.known_dir[ii];
-        if (kd == 1u) { same = (uint32_t)cnt[0]; opp = (uint32_t)cnt[1]; }
-        else if (kd == 2u) { same = (uint32_t)cnt[1]; opp = (uint32_t)cnt[0]; }
+    __shared__ unsigned long long s_votes[2];
+    if (threadIdx.x < 2u) s_votes[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long same = 0, opp = 0;
+    // (a fixed grid that walks the table: the vote leaves as two atomics per workgroup, not two per wave on one address)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < T.n_known; i += gridDim.x * 256u) {
+        const uint32_t row = T.known_kjidx[i];
+        int cnt[2];
+        cnt[0] = (int)T.known_cnt[row];
+        cnt[1] = (int)T.known_cnt[(uint64_t)T.n_kj + row];
+        const uint32_t kd = T.known_dir[i];
+        if (kd == 1u) { same += (uint32_t)cnt[0]; opp += (uint32_t)cnt[1]; }
+        else if (kd == 2u) { same += (uint32_t)cnt[1]; opp += (uint32_t)cnt[0]; }
+        if ((T.ablate & (1u | 64u)) || !(cnt[0] | cnt[1])) continue;
+        const uint64_t key = T.known_keys[i];
+        const uint64_t gl = key >> kJuncSpanBits, gr = gl + (key & ((1ull << kJuncSpanBits) - 1ull));
+        const uint64_t cl = plane_coord(T.pmap, gl), cr = plane_coord(T.pmap, gr);
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { same += __shfl_xor(same, d); opp += __shfl_xor(opp, d); }
-        if ((threadIdx.x & 63u) == 0u) {
-            if (same) atomicAdd(&T.dir_votes[0], same);
-            if (opp) atomicAdd(&T.dir_votes[1], opp);
+        for (uint32_t dir = 0; dir < 2u; dir++) {
+            const int c = cnt[dir];
+            if (!c) continue;
+            __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cl, -c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cr, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seg_add(T, dir, cl, -c);
+            seg_add(T, dir, cr, c);
+            mark_dirty(T, dir, cl);
+            mark_dirty(T, dir, cr);
         }
     }
-    if (!in || (T.ablate & (1u | 64u))) return;
-    const uint64_t key = T.known_keys[i];
-    const uint64_t gl = key >> kJuncSpanBits, gr = gl + (key & ((1ull << kJuncSpanBits) - 1ull));
-    const uint64_t cl = plane_coord(T.pmap, gl), cr = plane_coord(T.pmap, gr);
 #pragma unroll
-    for (uint32_t dir = 0; dir < 2u; dir++) {
-        const int c = cnt[dir];
-        if (!c) continue;
-        __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cl, -c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cr, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seg_add(T, dir, cl, -c);
-        seg_add(T, dir, cr, c);
-        mark_dirty(T, dir, cl);
-        mark_dirty(T, dir, cr);
+    for (int d = 32; d > 0; d >>= 1) { same += __shfl_xor(same, d); opp += __shfl_xor(opp, d); }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (same) atomicAdd(&s_votes[0], same);
+        if (opp) atomicAdd(&s_votes[1], opp);
     }
+    __syncthreads();
+    if (threadIdx.x < 2u && s_votes[threadIdx.x]) atomicAdd(&T.dir_votes[threadIdx.x], s_votes[threadIdx.x]);
 }
 
 // Zeroes the marked lines of the planes and the marks.  A lane reads 16 marks (a wave: 1024 marks = 512 lines of both
@@ -786,7 +789,8 @@ __global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* __restrict__
 
 void launch_known_junction_depth(const CountTables& T, hipStream_t s) {
     if (T.n_known == 0) return;
-    hipLaunchKernelGGL(known_junction_depth_kernel, dim3((T.n_known + 255u) / 256u), dim3(256), 0, s, T);
+    const uint32_t wgs = (T.n_known + 255u) / 256u;
+    hipLaunchKernelGGL(known_junction_depth_kernel, dim3(wgs < 256u ? wgs : 256u), dim3(256), 0, s, T);
 }
 
 void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride, hipStream_t s) {
