@@ -64,6 +64,23 @@ def decode_junction_keys(keys, chr_lens, owned):
     return chr_id, left, right, d
 
 
+def pack_tables(tables, keys):
+    """The named tables (one dtype) as one flat tensor, in the order of `keys`."""
+    import torch
+    return torch.cat([tables[k].reshape(-1) for k in keys])
+
+
+def unpack_tables(flat, tables, keys):
+    """Views of `flat` with the shapes of the named tables (inverse of pack_tables)."""
+    out, at = {}, 0
+    for k in keys:
+        n = tables[k].numel()
+        out[k] = flat[at:at + n].view(tables[k].shape)
+        at += n
+    assert at == flat.numel()
+    return out
+
+
 def gather_tables(tables, dist=None, root=0):
     """Collect the per-rank result tables on `root`.
 
@@ -83,25 +100,38 @@ def gather_tables(tables, dist=None, root=0):
         return out
     rank, world = dist.get_rank(), dist.get_world_size()
     out = {}
+    # On the device (RCCL) the fixed-shape tables of one dtype travel as ONE flat buffer: a collective's cost there is its
+    # launch, not its bytes (two reduces — fp64 columns, integer tables — instead of one per table).  Host tensors (gloo:
+    # tests and rehearsals) go one by one: gloo is slower on the concatenated buffer (measured: 45 vs 20 ms, world 2).
+    by_dtype = {}
     for k in fixed:
-        t = tables[k].contiguous()
-        dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
-        out[k] = t
-    # junctions: lengths, then padded gather
-    n_local = torch.tensor([tables["junc_keys"].numel()], dtype=torch.int64, device=tables["junc_keys"].device)
+        if tables[k].is_cuda:
+            by_dtype.setdefault(tables[k].dtype, []).append(k)
+        else:
+            t = tables[k].contiguous()
+            dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+            out[k] = t
+    for dt, ks in by_dtype.items():
+        flat = pack_tables(tables, ks)
+        dist.reduce(flat, dst=root, op=dist.ReduceOp.SUM)
+        out.update(unpack_tables(flat, tables, ks))
+    # junctions: lengths, then ONE padded gather of keys and counts (both as int64)
+    keys, counts = tables["junc_keys"], tables["junc_counts"]
+    n_local = torch.tensor([keys.numel()], dtype=torch.int64, device=keys.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)
     sizes = [int(s.item()) for s in sizes]
     m = max(max(sizes), 1)
-    for name, dt in (("junc_keys", torch.int64), ("junc_counts", torch.int32)):
-        pad = torch.zeros(m, dtype=dt, device=tables[name].device)
-        pad[: sizes[rank]] = tables[name]
-        if rank == root:
-            bufs = [torch.zeros_like(pad) for _ in range(world)]
-            dist.gather(pad, bufs, dst=root)
-            out[name] = [b[:s] for b, s in zip(bufs, sizes)]
-        else:
-            dist.gather(pad, None, dst=root)
+    pad = torch.zeros(2 * m, dtype=torch.int64, device=keys.device)
+    pad[: sizes[rank]] = keys
+    pad[m: m + sizes[rank]] = counts.to(torch.int64)
+    if rank == root:
+        bufs = [torch.zeros_like(pad) for _ in range(world)]
+        dist.gather(pad, bufs, dst=root)
+        out["junc_keys"] = [b[:s] for b, s in zip(bufs, sizes)]
+        out["junc_counts"] = [b[m: m + s].to(torch.int32) for b, s in zip(bufs, sizes)]
+    else:
+        dist.gather(pad, None, dst=root)
     return out if rank == root else None
 
 

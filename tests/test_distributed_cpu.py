@@ -84,3 +84,19 @@ def test_gloo_sharded_run_equals_single_run(world, stranded, tmp_path):
                 exp.append((int(r["junc_chr"][j]), int(r["junc_left"][j]), int(r["junc_right"][j]), d, int(r["junc_cnt"][d, j])))
     assert got["junc"] == sorted(exp)
     assert len(got["masks"]) == world
+
+
+def test_pack_and_unpack_of_the_fixed_tables_are_inverse():
+    """gather_tables sends the device-resident tables of one dtype as one flat buffer (one RCCL reduce instead of one per
+    table): packing and unpacking must be exact inverses for the shapes it meets ([8,n], [6,n], flat, empty)."""
+    import torch
+    from irfinder_amd.distributed import pack_tables, unpack_tables
+    g = torch.Generator().manual_seed(3)
+    tabs = {"ir_u32": torch.randint(0, 1 << 30, (6, 17), generator=g, dtype=torch.int32), "sp_cnt": torch.randint(0, 99, (11,), generator=g, dtype=torch.int32),
+            "roi_cnt": torch.zeros(0, dtype=torch.int32), "known_cnt": torch.randint(0, 99, (2, 5), generator=g, dtype=torch.int32)}
+    keys = list(tabs)
+    flat = pack_tables(tabs, keys)
+    assert flat.numel() == sum(t.numel() for t in tabs.values())
+    back = unpack_tables(flat + 0, tabs, keys)
+    for k in keys:
+        assert back[k].shape == tabs[k].shape and torch.equal(back[k], tabs[k]), k
