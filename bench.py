@@ -219,19 +219,25 @@ def main():
             out["got"] = irfdist.gather_tables(tabs, None)
             t_d = time.perf_counter()
         else:
-            tabs = {
-                "ir_f64": export(COL_IR_NONDIR_F64, (8, n_in), torch.float64),
-                "ir_u32": export(COL_IR_NONDIR_U32, (6, n_in), torch.int32),
-                "sp_cnt": export(COL_SP_CNT, None, torch.int32),
-                "roi_cnt": export(COL_ROI_CNT, None, torch.int32),
-                "chr_cnt": export(COL_CHR_CNT, None, torch.int32),
-                "known_cnt": export(COL_KNOWN_CNT, None, torch.int32),
-                "junc_keys": export(COL_JUNC_KEYS, None, torch.int64),
-                "junc_counts": export(COL_JUNC_COUNTS, None, torch.int32),
-            }
+            # every column is only queued (IRF_COL_NO_SYNC) into device buffers that are allocated once; one wait, then the
+            # collectives (which run on torch's streams: the engine's stream must be idle before they start)
+            keep = out.setdefault("mg", {})
+            tabs = {}
+            cols = [("ir_f64", COL_IR_NONDIR_F64, (8, n_in), torch.float64), ("ir_u32", COL_IR_NONDIR_U32, (6, n_in), torch.int32),
+                    ("sp_cnt", COL_SP_CNT, None, torch.int32), ("roi_cnt", COL_ROI_CNT, None, torch.int32), ("chr_cnt", COL_CHR_CNT, None, torch.int32),
+                    ("known_cnt", COL_KNOWN_CNT, None, torch.int32), ("junc_keys", COL_JUNC_KEYS, None, torch.int64), ("junc_counts", COL_JUNC_COUNTS, None, torch.int32)]
             if eng.export_size(COL_IR_DIR_F64):
-                tabs["ir_dir_f64"] = export(COL_IR_DIR_F64, (8, n_in), torch.float64)
-                tabs["ir_dir_u32"] = export(COL_IR_DIR_U32, (6, n_in), torch.int32)
+                cols += [("ir_dir_f64", COL_IR_DIR_F64, (8, n_in), torch.float64), ("ir_dir_u32", COL_IR_DIR_U32, (6, n_in), torch.int32)]
+            for key, col, shape, dt in cols:
+                n = eng.export_size(col)
+                t = keep.get(key)
+                if t is None or t.numel() != n:
+                    t = keep[key] = torch.empty(n, dtype=dt, device=dev)
+                if n:
+                    ir = key.startswith("ir_")
+                    eng.export_device(col | COL_NO_SYNC | (COL_KEEP_ORPHANS if ir and rank == 0 else 0), t.data_ptr())
+                tabs[key] = t.view(*shape) if shape else t
+            eng.sync()
             if coll_dev.type == "cpu":
                 tabs = {k: t.cpu() for k, t in tabs.items()}
             got = irfdist.gather_tables(tabs, dist)
