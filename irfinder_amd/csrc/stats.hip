@@ -656,9 +656,19 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
         unsigned long long pre_sum;
         block_excl_scan<kWaves>(tot, tsum, pre, pre_sum, s_wc, s_ws);
         if (tid == kThreads - 1) s_total = pre_sum + tsum;       // sum of all depths
-        // the thread whose bins hold rank r is found by a ballot; then the lanes of its wave take one of its bins each
+        // the thread whose bins hold rank r is found by a ballot; then the lanes of its wave take one of its bins each.
+        // The second rank of a percentile (q = 3, 5, 7: rank k after rank k - 1, kernels.h: stats_queries) mostly lies in
+        // the same bin as the first: the wave that answered the first one then answers it from what it kept.
+        bool prev_here = false;             // this wave answered query q - 1 ...
+        uint32_t prev_left = 0, prev_bin = 0;   // ... and its bin holds prev_left more ranks behind that one
         for (int q = 0; q < kQueries; q++) {
-            if (!((qneed >> q) & 1u)) continue;                                    // wave-uniform
+            if (!((qneed >> q) & 1u)) { prev_here = false; continue; }             // wave-uniform
+            if (q >= 3 && (q & 1) && prev_here && prev_left > 0u) {
+                if (lane == 0) s_qval[q] = prev_bin;                               // (the sums of q >= 2 are never read)
+                prev_here = false;
+                continue;
+            }
+            prev_here = false;
             const uint32_t r = lane_u32(recA, 16u + q);
             const uint64_t own = __ballot(r >= pre && r - pre < tot);
             if (!own) continue;                                                    // another wave's bins
@@ -678,6 +688,9 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
                 s_qval[q] = (uint32_t)bin;
                 s_qsum[q] = o_psum + (unsigned long long)base * ex_c + ex_w + bin * (unsigned long long)(rr - ex_c);
             }
+            prev_here = true;
+            prev_bin = (uint32_t)bin;
+            prev_left = lane_u32(ic, hl) - 1u - rr;                                // ranks of this bin behind rank r
         }
         __syncthreads();
     } else if (N > 0) {
