@@ -52,8 +52,12 @@ __device__ uint32_t g_cprof[1024][8];
 #ifndef K_THREADS
 #define K_THREADS 256
 #endif
+// Four workgroups per CU: a chunk is a chain of dependent phases (columns -> LDS facts -> bucket entries -> key / point
+// tables -> LDS atomics -> flush), and what a CU gets done is the number of chunks it has in flight (2 workgroups: 5.5 ms,
+// 3: 3.03 ms, 4: 2.75 ms).  That takes <= 40 KB of LDS (a 2048-position window instead of 4096: 39.8 KB) and <= 128
+// registers (168 wanted: 27 spilled, almost all of them outside the block loop).
 #ifndef K_WIN
-#define K_WIN 4096
+#define K_WIN 2048
 #endif
 #ifndef K_LINES
 #define K_LINES 128
@@ -65,10 +69,10 @@ __device__ uint32_t g_cprof[1024][8];
 #define K_NOVELQ 256
 #endif
 #ifndef K_WGS_PER_CU
-#define K_WGS_PER_CU 3
+#define K_WGS_PER_CU 4
 #endif
 #ifndef K_MIN_WGS
-#define K_MIN_WGS 3
+#define K_MIN_WGS 4
 #endif
 constexpr int kThreads = K_THREADS;
 #ifndef K_VEC
