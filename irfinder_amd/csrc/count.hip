@@ -98,7 +98,10 @@ constexpr uint32_t kJCache = K_JCACHE;   // LDS cache of known-junction counters
 constexpr uint32_t kEmpty = 0xffffffffu;
 constexpr uint32_t kLines = K_LINES;     // LDS cache of 16-position lines of the difference planes outside the window
 constexpr uint32_t kWin = K_WIN;         // positions of the LDS difference-array window (both strands in one int32)
-constexpr uint32_t kPCache = 128;         // LDS cache of SpansPoint counters (direct-mapped on the point index)
+#ifndef K_PCACHE
+#define K_PCACHE 128
+#endif
+constexpr uint32_t kPCache = K_PCACHE;         // LDS cache of SpansPoint counters (direct-mapped on the point index)
 constexpr uint32_t kNovelQ = K_NOVELQ;   // LDS queue of novel-junction events per chunk (those the table below has no room for)
 constexpr uint32_t kNovelH = 128;        // LDS table that merges a chunk's novel-junction events by key (open addressing, 4 probes)
 constexpr unsigned long long kEmpty64 = ~0ull;     // (no event has bit 63 set)
