@@ -113,7 +113,7 @@ struct irf_ctx {
     // irf_set_input_order(IRF_ORDER_ANY): every batch is binned by coordinate before it is counted (reorder.hip)
     uint32_t input_order = 0;
     DevBuf<uint64_t> ro_key_a, ro_key_b;
-    DevBuf<uint32_t> ro_idx_a, ro_idx_b, ro_nblk, ro_chr, ro_start, ro_end, ro_off, ro_bs, ro_bl;
+    DevBuf<uint32_t> ro_nblk, ro_chr, ro_start, ro_end, ro_off, ro_bs, ro_bl;
     DevBuf<uint8_t> ro_flags, ro_rd, ro_frag_recs;
     DevBuf<uint2> ro_blk_recs;
     DevBuf<uint32_t> ro_src_off;
@@ -879,8 +879,6 @@ int irf_ctx::reorder(dev::BatchDev& B) {
     const size_t n = B.n_frag, nb = std::max<uint32_t>(B.n_blk, 1);
     hipError_t e = ro_key_a.reserve(n);
     if (e == hipSuccess) e = ro_key_b.reserve(n);
-    if (e == hipSuccess) e = ro_idx_a.reserve(n);
-    if (e == hipSuccess) e = ro_idx_b.reserve(n);
     if (e == hipSuccess) e = ro_nblk.reserve(n + 1);
     if (e == hipSuccess) e = ro_off.reserve(n + 4);
     if (e == hipSuccess) e = ro_chr.reserve(n + 4);
@@ -896,15 +894,14 @@ int irf_ctx::reorder(dev::BatchDev& B) {
     const uint64_t ws_need = std::max(dev::radix_workspace_elems(n), dev::scan_workspace_elems(n + 1));
     if (e == hipSuccess && ws_need > d_ws_sort.cap) e = d_ws_sort.reserve(ws_need);
     if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the batch reorder buffers failed");
-    dev::launch_reorder_keys(B, d_chr_base.p, n_chr, ro_key_a.p, ro_idx_a.p, ro_frag_recs.p, ro_blk_recs.p, d_err.p, stream);
+    dev::launch_reorder_keys(B, d_chr_base.p, n_chr, ro_key_a.p, ro_frag_recs.p, ro_blk_recs.p, d_err.p, stream);
     uint64_t* ks = ro_key_a.p; uint64_t* kd = ro_key_b.p;
-    uint32_t* is = ro_idx_a.p; uint32_t* id = ro_idx_b.p;
-    const uint64_t top = full_size >> dev::kReorderShift;
-    for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += 8) {
-        dev::launch_radix_pass(ks, kd, is, id, n, shift, d_ws_sort.p, stream);
-        std::swap(ks, kd); std::swap(is, id);
+    const uint64_t top = full_size >> dev::kReorderShift;        // (the bin sits in bits 32 and up, the fragment index below it)
+    for (int shift = 0; shift < 32 && (top >> shift) != 0; shift += 8) {
+        dev::launch_radix_pass(ks, kd, nullptr, nullptr, n, 32 + shift, d_ws_sort.p, stream);
+        std::swap(ks, kd);
     }
-    dev::launch_reorder_frags(B.n_frag, ro_frag_recs.p, is, ro_chr.p, ro_flags.p, ro_start.p, ro_end.p, ro_nblk.p, ro_src_off.p, stream);
+    dev::launch_reorder_frags(B.n_frag, ro_frag_recs.p, ks, ro_chr.p, ro_flags.p, ro_start.p, ro_end.p, ro_nblk.p, ro_src_off.p, stream);
     dev::launch_exclusive_scan_u32(ro_nblk.p, ro_off.p, n + 1, d_ws_sort.p, stream);
     dev::launch_reorder_blocks(B.n_frag, ro_blk_recs.p, ro_src_off.p, ro_off.p, ro_bs.p, ro_bl.p, ro_rd.p, stream);
     HIP_TRY(hipGetLastError());

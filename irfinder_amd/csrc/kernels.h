@@ -119,13 +119,14 @@ inline size_t dirty_map_bytes(uint64_t plane_stride) { return (size_t)((plane_st
 
 // ---- batches in any order (reorder.hip) -------------------------------------
 constexpr int kReorderShift = 8;       // fragments are binned by (chromosome base + start) >> kReorderShift
-// keys + indices for the radix passes, and the array-of-structs copies the two gathers read (frag_recs: n_frag records of
+// keys for the radix passes (bin << 32 | fragment index: the index travels in the key, the passes move 8 bytes per
+// record and sort on bits 32 and up), and the array-of-structs copies the two gathers read (frag_recs: n_frag records of
 // reorder_frag_rec_bytes(), blk_recs: n_blk x 8 bytes); checks the CSR offsets (ERR_CSR) and the packed block fields
 size_t reorder_frag_rec_bytes();
-void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, uint32_t* idx, void* frag_recs, void* blk_recs,
+void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, void* frag_recs, void* blk_recs,
                          uint32_t* err_flags, hipStream_t s);
 // nblk: n_frag + 1 elements (the last one 0: its exclusive scan is the new offsets array, total included)
-void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint32_t* perm, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
+void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint64_t* sorted_keys, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
                           uint32_t* nblk, uint32_t* src_off, hipStream_t s);
 void launch_reorder_blocks(uint32_t n_frag, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
                            hipStream_t s);
@@ -146,7 +147,7 @@ constexpr uint32_t kRadixTile = 4096;
 uint64_t radix_workspace_elems(uint64_t n);     // uint32 elements
 // OR / AND over all keys (to skip constant digits); out[0] = OR, out[1] = AND (pre-set to 0 / ~0)
 void launch_key_bits(const uint64_t* keys, uint64_t n, unsigned long long* out, hipStream_t s);
-// one stable counting pass on digit [shift, shift+8); the weights travel with their keys
+// one stable counting pass on digit [shift, shift+8); the weights travel with their keys (win = wout = nullptr: keys only)
 void launch_radix_pass(const uint64_t* in, uint64_t* out, const uint32_t* win, uint32_t* wout, uint64_t n, int shift,
                        uint32_t* workspace, hipStream_t s);
 // sorted keys -> head flags (1 where key differs from predecessor)

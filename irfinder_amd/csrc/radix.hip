@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
         const uint64_t i = base + (uint64_t)it * 64u;
         const bool valid = i < n;
         key[it] = valid ? in[i] : 0ull;
-        wgt[it] = valid ? win[i] : 0u;
+        wgt[it] = (valid && win) ? win[i] : 0u;           // (win == nullptr: keys only)
         const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
             const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
             const uint32_t o = s_cnt[wave][d] + rank[it];
             out[o] = key[it];
-            wout[o] = wgt[it];
+            if (wout) wout[o] = wgt[it];
         }
     }
 }

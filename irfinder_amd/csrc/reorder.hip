@@ -5,7 +5,7 @@
 // (the order irf_dreader_* delivers without the name join; upstream's own input order) scatters every chunk over the
 // whole genome: seven times the kernel's time.  All outputs are commutative sums, so the engine may count
 // the fragments in any order it likes: with irf_set_input_order(IRF_ORDER_ANY) every batch is binned by
-// (chromosome base + start) >> kReorderShift with the radix passes of radix.hip (key = bin, payload = fragment index),
+// (chromosome base + start) >> kReorderShift with the radix passes of radix.hip (key = bin << 32 | fragment index),
 // its columns are gathered into that order, and the count kernel runs on the copy.  No upstream counterpart.
 #include "kernels.h"
 
@@ -23,13 +23,12 @@ struct __attribute__((aligned(32))) FragRec { uint32_t chr, start, end, off0, nb
 constexpr uint32_t kReadShift = 30;          // BlkRec8.y = len | read << 30
 
 __global__ __launch_bounds__(kThreads) void reorder_keys_kernel(BatchDev B, const uint64_t* __restrict__ chr_base, uint32_t n_chr,
-                                                                uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, FragRec* __restrict__ recs,
-                                                                uint32_t* err_flags) {
+                                                                uint64_t* __restrict__ keys, FragRec* __restrict__ recs, uint32_t* err_flags) {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= B.n_frag) return;
     const uint32_t c = B.frag_chr[i], st = B.frag_start[i];
-    keys[i] = c < n_chr ? (chr_base[c] + st) >> kReorderShift : 0ull;      // (a bad id is reported by the count kernel)
-    idx[i] = i;
+    const uint64_t bin = c < n_chr ? (chr_base[c] + st) >> kReorderShift : 0ull;      // (a bad id is reported by the count kernel)
+    keys[i] = bin << 32 | i;
     const uint32_t o0 = B.frag_blk_off[i], o1 = B.frag_blk_off[i + 1u];
     // ERR_CSR as the count kernel reports it in sorted mode: not non-decreasing, beyond n_blk, not spanning [0, n_blk];
     // a fragment with bad offsets gets no blocks, so nothing is read out of bounds
@@ -50,13 +49,13 @@ __global__ __launch_bounds__(kThreads) void reorder_pack_blocks_kernel(BatchDev 
 }
 
 // fragment columns in the new order, the block count of every fragment and where its blocks lie in the old order
-__global__ __launch_bounds__(kThreads) void reorder_frags_kernel(uint32_t n_frag, const FragRec* __restrict__ recs, const uint32_t* __restrict__ perm,
+__global__ __launch_bounds__(kThreads) void reorder_frags_kernel(uint32_t n_frag, const FragRec* __restrict__ recs, const uint64_t* __restrict__ sorted_keys,
                                                                  uint32_t* __restrict__ chr, uint8_t* __restrict__ flags, uint32_t* __restrict__ start,
                                                                  uint32_t* __restrict__ end, uint32_t* __restrict__ nblk, uint32_t* __restrict__ src_off) {
     const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
     if (j > n_frag) return;
     if (j == n_frag) { nblk[j] = 0u; return; }           // (the scan's last element: the total lands behind it)
-    const FragRec r = recs[perm[j]];
+    const FragRec r = recs[(uint32_t)sorted_keys[j]];
     chr[j] = r.chr;
     flags[j] = (uint8_t)r.flags;
     start[j] = r.start;
@@ -86,16 +85,16 @@ __global__ __launch_bounds__(kThreads) void reorder_blocks_kernel(uint32_t n_fra
 
 size_t reorder_frag_rec_bytes() { return sizeof(FragRec); }
 
-void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, uint32_t* idx, void* frag_recs, void* blk_recs,
+void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, void* frag_recs, void* blk_recs,
                          uint32_t* err_flags, hipStream_t s) {
-    hipLaunchKernelGGL(reorder_keys_kernel, dim3((B.n_frag + kThreads - 1) / kThreads), dim3(kThreads), 0, s, B, chr_base, n_chr, keys, idx,
+    hipLaunchKernelGGL(reorder_keys_kernel, dim3((B.n_frag + kThreads - 1) / kThreads), dim3(kThreads), 0, s, B, chr_base, n_chr, keys,
                        static_cast<FragRec*>(frag_recs), err_flags);
     if (B.n_blk) hipLaunchKernelGGL(reorder_pack_blocks_kernel, dim3((B.n_blk + kThreads - 1) / kThreads), dim3(kThreads), 0, s, B, static_cast<uint2*>(blk_recs), err_flags);
 }
 
-void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint32_t* perm, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
+void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint64_t* sorted_keys, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
                           uint32_t* nblk, uint32_t* src_off, hipStream_t s) {
-    hipLaunchKernelGGL(reorder_frags_kernel, dim3(n_frag / kThreads + 1u), dim3(kThreads), 0, s, n_frag, static_cast<const FragRec*>(frag_recs), perm, chr, flags,
+    hipLaunchKernelGGL(reorder_frags_kernel, dim3(n_frag / kThreads + 1u), dim3(kThreads), 0, s, n_frag, static_cast<const FragRec*>(frag_recs), sorted_keys, chr, flags,
                        start, end, nblk, src_off);
 }
 
