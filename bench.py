@@ -402,7 +402,7 @@ def main():
                 g_col, c_col = np.asarray(gres[tname][k])[rows], np.asarray(cres[tname][k])
                 if len(g_col) != len(c_col) or not np.array_equal(g_col, c_col):
                     diff.append("%s.%s" % (tname, k))
-        compared = ["%d IR rows x %d columns" % (len(rows), len(IR_F64) + len(IR_U32) + 1)]
+        compared = ["%d IR rows x %d columns%s" % (len(rows), len(IR_F64) + len(IR_U32) + 1, " of both tables (nondir, dir)" if gres["has_dir"] else "")]
         if whole:
             for k in ("directionality", "n_fragments", "n_blocks", "n_junction_events"):
                 if gres[k] != cres[k]:
