@@ -5,33 +5,36 @@
 // FragmentsInChr / FragmentsInROI / JunctionCount / SpansPoint and of
 // ReadBlockProcessor_CoverageBlocks.cpp CoverageBlocks (+ FragmentsMap):
 //   * FragmentsInChr : wave-aggregated LDS histogram per workgroup, flushed with global atomics
-//   * FragmentsInROI : bucket index over the end-sorted ROI table + short walk
+//   * FragmentsInROI : one bucket-table record (the candidate ROI inline) per fragment
 //   * CoverageBlocks : +1 / -1 into the per-strand difference array (depth comes
 //                      from the prefix scan at finalize)
-//   * SpansPoint     : bucket table + short walk of the sorted points
-//   * JunctionCount  : events on a known junction (ref-sj.ref) bump that junction's
-//                      counter (bucket table + walk; LDS-cached per chunk); novel junctions
-//                      are appended as packed (chr,left,span,strand) events to a
-//                      buffer and sort-reduced at finalize
+//   * SpansPoint     : the difference of two point ranks, both from the cell records the
+//                      difference events need anyway (kernels.h: cell tables)
+//   * JunctionCount  : one probe of a sparse hash table of the known junctions (ref-sj.ref);
+//                      a hit bumps that junction's counter (LDS-cached), novel junctions are
+//                      merged per slice in an LDS table, appended as packed
+//                      (chr,left,span,strand) records and sort-reduced at finalize
 // All outputs are commutative integer sums, so any batch order gives identical
-// results.  Integer work bound by memory latency and by the atomic rate: no MFMA.
+// results.  Integer work bound by memory latency and by the vector-memory instruction rate: no MFMA.
 //
-// Shape of the kernel.  The input is CSR (fragments -> blocks).  A workgroup processes a chunk of kChunk consecutive
-// fragments in bulk phases, so that every lane has many independent, wide loads in flight:
-//   1. fragment-parallel, 4 consecutive fragments per lane (16-byte loads of the fragment columns): per-fragment
-//      facts (chromosome base, strand, chromosome length, CSR offset) go to LDS; FragmentsInChr and
-//      FragmentsInROI are done here;
-//   2. block-parallel, 4 consecutive blocks per lane (16-byte loads of the block columns): the owning fragment comes
-//      from a binary search of the LDS offsets; ONE 16-byte bucket-table entry per block end gives the plane map,
-//      the SpansPoint range and the known-junction range.  A block owns the junction to its right, and with it
-//      the two difference events next to that junction (its own end, its successor's start): a read on a known
-//      junction costs one wave-aggregated LDS increment of that junction's counter, and the junction's two
-//      difference events are emitted once per chunk from the counter;
-//   3. the LDS accumulators are flushed with global atomics shaped for the memory-side atomic unit (consecutive
-//      lanes = consecutive cells, whole 64-byte lines): the difference window (both strands packed in one int32
-//      per position), the line-granular cache of far events, the junction cache, the novel-junction queue.
-// Loads are unconditional on clamped indices: a conditional load compiles to a branch with a full vmcnt wait
-// behind it, which serialises the round trips.
+// Shape of the kernel (round 3: the block phase no longer searches).  The input is CSR (fragments -> blocks).  A
+// workgroup takes SLICES of the (coordinate-sorted) batch, kSlice chunks of 256 consecutive fragments each, and keeps its
+// LDS accumulators across the chunks of a slice:
+//   F. fragment phase, one fragment per lane: the chromosome record, FragmentsInChr, FragmentsInROI; the fragment's
+//      facts (coordinate base, strand, chromosome length) go to LDS and the lane writes its id over the OWNER entries of
+//      its blocks (with a first / last flag), so that
+//   B. the block phase, one block per lane in strides of 63 (lane 63 only looks ahead), needs no search for the owning
+//      fragment: one LDS read gives the owner, one its facts.  Every table question about a position is one 16-byte
+//      cell record: the cell of the block start and the cell of the block end give both plane coordinates and both
+//      SpansPoint ranks; the junction to the right of the block is one probe of the hash table.  Three table loads per
+//      block, all independent of each other.  The successor block's columns, validity and start cell come from the next
+//      lane by DPP.  A block owns the junction to its right and the two difference events next to it (its own end, its
+//      successor's start): a read on a known junction costs one LDS increment of that junction's counter, which also
+//      stands for both events (known_junction_depth_kernel applies them once per junction at finalize).
+//   The difference window is circular (cell = plane position mod kWin) and SCROLLS with the chunks: what a chunk's first
+//   fragment leaves behind is flushed (one global atomic per non-zero cell, whole 64-byte lines), the rest stays and keeps
+//   merging events of later chunks; caches of far lines, junction counters, point counters and novel junctions are flushed
+//   every kFlushEvery chunks.
 #include "kernels.h"
 
 #include <cstdio>
@@ -42,20 +45,13 @@ namespace dev {
 namespace {
 
 #ifdef COUNT_PROF
-// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of wave 0 per phase and workgroup
-__device__ uint32_t g_cprof[1024][8];
-#define CPROF(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
+// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of waves 0 and 3 per phase and workgroup
+__device__ uint32_t g_cprof[2048][2][8];
+#define CPROF(k) do { if (lane == 0u && (wave == 0u || wave == 3u)) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
 #else
 #define CPROF(k) do { } while (0)
 #endif
 
-#ifndef K_THREADS
-#define K_THREADS 256
-#endif
-// Four workgroups per CU: a chunk is a chain of dependent phases (columns -> LDS facts -> bucket entries -> key / point
-// tables -> LDS atomics -> flush), and what a CU gets done is the number of chunks it has in flight (2 workgroups: 5.5 ms,
-// 3: 3.03 ms, 4: 2.75 ms).  That takes <= 40 KB of LDS (a 2048-position window instead of 4096: 39.8 KB) and <= 128
-// registers (168 wanted: 27 spilled, almost all of them outside the block loop).
 #ifndef K_WIN
 #define K_WIN 2048
 #endif
@@ -65,66 +61,68 @@ __device__ uint32_t g_cprof[1024][8];
 #ifndef K_JCACHE
 #define K_JCACHE 256
 #endif
-#ifndef K_NOVELQ
-#define K_NOVELQ 256
-#endif
-#ifndef K_WGS_PER_CU
-#define K_WGS_PER_CU 4
-#endif
-#ifndef K_MIN_WGS
-#define K_MIN_WGS 4
-#endif
-constexpr int kThreads = K_THREADS;
-#ifndef K_VEC
-#define K_VEC 4
-#endif
-constexpr int kVec = K_VEC;                           // consecutive fragments / blocks per lane (4: 16-byte loads, 2: 8-byte loads)
-static_assert(kVec == 4 || kVec == 2, "K_VEC");
-// a lane's kVec consecutive elements of a uint32 / uint8 column in one load
-template <int V> struct VecT;
-template <> struct VecT<4> { typedef uint4 u32v; typedef uint32_t u8v; };
-template <> struct VecT<2> { typedef uint2 u32v; typedef uint16_t u8v; };
-typedef VecT<kVec>::u32v U32V;
-typedef VecT<kVec>::u8v U8V;
-struct __attribute__((aligned(4))) Quad { uint32_t v[4]; };      // four consecutive table entries at any dword
-__device__ __forceinline__ void unpack(const uint4& v, uint32_t* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-__device__ __forceinline__ void unpack(const uint2& v, uint32_t* o) { o[0] = v.x; o[1] = v.y; }
-constexpr int kVecLog2 = kVec == 4 ? 2 : 1;
-constexpr int kChunk = kThreads * kVec;               // fragments per workgroup iteration
-constexpr int kChunkLog2 = kChunk == 1024 ? 10 : kChunk == 2048 ? 11 : kChunk == 512 ? 9 : 0;
-static_assert(kChunkLog2 > 0, "K_THREADS");
-constexpr int kChrBins = 512;       // LDS histogram covers refIDs < 256; larger ones go straight to global
-constexpr uint32_t kJCache = K_JCACHE;   // LDS cache of known-junction counters (direct-mapped on the known-key index)
-constexpr uint32_t kEmpty = 0xffffffffu;
-constexpr uint32_t kLines = K_LINES;     // LDS cache of 16-position lines of the difference planes outside the window
-constexpr uint32_t kWin = K_WIN;         // positions of the LDS difference-array window (both strands in one int32)
 #ifndef K_PCACHE
 #define K_PCACHE 128
 #endif
-constexpr uint32_t kPCache = K_PCACHE;         // LDS cache of SpansPoint counters (direct-mapped on the point index)
-constexpr uint32_t kNovelQ = K_NOVELQ;   // LDS queue of novel-junction events per chunk (those the table below has no room for)
-constexpr uint32_t kNovelH = 128;        // LDS table that merges a chunk's novel-junction events by key (open addressing, 4 probes)
-constexpr unsigned long long kEmpty64 = ~0ull;     // (no event has bit 63 set)
-constexpr uint32_t kWinMaxBlocks = 16000;   // more blocks than this in one chunk: a packed 16-bit counter could overflow
-constexpr uint32_t kFragValid = 1u << 31, kFragDir = 1u << 30, kFragBaseMask = (1u << 30) - 1u;   // base is a multiple of 64
+#ifndef K_TILE
+#define K_TILE 1024
+#endif
+#ifndef K_SLICE
+#define K_SLICE 16
+#endif
+#ifndef K_FLUSH
+#define K_FLUSH 4
+#endif
+#ifndef K_WGS_PER_CU
+#define K_WGS_PER_CU 5
+#endif
+#ifndef K_BU
+#define K_BU 2
+#endif
+constexpr int kThreads = 256;
+constexpr uint32_t kWaves = kThreads / 64;
+constexpr uint32_t kChunk = kThreads;               // fragments per chunk: one per lane
+constexpr uint32_t kTile = K_TILE;                  // owner entries: blocks of a chunk are processed in tiles of this many
+constexpr uint32_t kSlice = K_SLICE;                // chunks per slice (a workgroup's unit of work; accumulators live this long)
+constexpr uint32_t kFlushEvery = K_FLUSH;           // chunks between two flushes of the caches
+constexpr int kBU = K_BU;                           // strides a wave works on at once (their table loads are in flight together)
+constexpr uint32_t kStride = 63;                    // blocks per wave and step (lane 63 is the look-ahead)
+constexpr uint32_t kChrBins = 128;                  // LDS histogram covers refIDs < 64; larger ones go straight to global
+constexpr uint32_t kJCache = K_JCACHE;              // LDS cache of known-junction counters (direct-mapped on the junction's row)
+constexpr uint32_t kEmpty = 0xffffffffu;
+constexpr uint32_t kLines = K_LINES;                // LDS cache of 16-position lines of the difference planes outside the window
+constexpr uint32_t kWin = K_WIN;                    // positions of the LDS difference-array window (both strands in one int32)
+constexpr uint32_t kPCache = K_PCACHE;              // LDS cache of SpansPoint counters (direct-mapped on the point index)
+constexpr uint32_t kNovelQ = 64;                    // LDS queue of novel-junction events (those the table below has no room for)
+constexpr uint32_t kNovelH = 128;                   // LDS table that merges novel-junction events by key (open addressing, 4 probes)
+constexpr unsigned long long kEmpty64 = ~0ull;      // (no event has bit 63 set)
+// The window and the line cache keep both strands of a position as 16-bit halves of one word.  A chunk with more blocks than
+// kWinMaxBlocks bypasses them; everything is flushed before the events added since the last complete flush can exceed 2^15.
+constexpr uint32_t kWinMaxBlocks = 4000;
+constexpr uint32_t kEvFlush = 22000;                // + 2 * kWinMaxBlocks < 32768
+constexpr unsigned long long kNoWin = ~0ull;
+constexpr uint32_t kFragValid = 1u << 31, kFragDir = 1u << 30, kFragBaseMask = (1u << 28) - 1u;   // base >> 6 (base is a multiple of 64, < 2^34)
+constexpr uint32_t kOwnFirst = 0x4000u, kOwnLast = 0x8000u;
+static_assert(kWin % 64u == 0u && (kWin & (kWin - 1u)) == 0u, "K_WIN");
+static_assert((kLines * 16u) % kThreads == 0u, "the line flush runs with whole waves (DPP sums)");
+static_assert(kEvFlush + 2u * kWinMaxBlocks < 32768u, "packed 16-bit halves");
 
 struct Lds {
-    uint32_t off[kChunk + 4];          // CSR offsets of the chunk's fragments (clamped to n_blk); [kChunk] = end
-    uint32_t fb[kChunk];               // chr_base >> 6 | strand << 30 | counted << 31
-    uint32_t fclen[kChunk];            // chromosome length
+    uint2 facts[kChunk];               // x = base >> 6 | strand << 30 | counted << 31, y = chromosome length
+    uint16_t owner[kTile + 2];         // per block of the tile: lane of the owning fragment | first << 14 | last << 15
     int32_t tile[kWin + 64];           // difference window: low half strand 0, high half strand 1 (+ one idle cell per lane)
     uint32_t ltag[kLines];             // far-event line cache: plane position >> 4
-    int32_t lcnt[kLines + 1][16];      // both strands of a position in one word, as in the window (low half strand 0); line kLines: idle
-    uint32_t jtag[kJCache];            // known-junction cache: index into known_keys
+    int32_t lcnt[kLines + 1][16];      // both strands of a position in one word, as in the window; line kLines: idle
+    uint32_t jtag[kJCache];            // known-junction cache: row of the known-junction table
     uint32_t jcnt[2][kJCache];
-    uint32_t ptag[kPCache];            // SpansPoint cache: index into sp_pos32
+    uint32_t ptag[kPCache];            // SpansPoint cache: index of the point among the points on owned chromosomes
     uint32_t pcnt[2][kPCache];
     unsigned long long nq[kNovelQ];
     unsigned long long nh_key[kNovelH];
     uint32_t nh_cnt[kNovelH];
     uint32_t chr[kChrBins];
-    unsigned long long win, nq_base;
-    uint32_t nq_n, nh_n, wmax;
+    uint32_t wmax[2];                  // highest window offset + 1 a chunk touched
+    uint32_t nq_n, nh_n;
 };
 
 // Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
@@ -142,6 +140,31 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
     return v;
 }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {          // lane 63 ends up with the wave's maximum
+    v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+// Workgroup barrier with the wave's own LDS operations (the block phase's atomics among them) completed first.  The wait is
+// spelled out: in front of a barrier at a loop header the compiler was seen to emit none (ROCm 7.2, gfx950: s_barrier right
+// behind the back edge's ds_max_u32), and a read behind the barrier then missed an update issued in front of it.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+// lane i gets lane i + 1's value (lane 63: 0); every lane of the wave must be active
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) {
+#ifdef K_NO_WAVE_SHL
+    return (uint32_t)__shfl_down((int)v, 1);
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);     // wave_shl:1
+#endif
+}
 
 // The sum of every 256-position segment of the planes is kept next to them (seg_sum; its exclusive scan is the depth
 // carry of stats.hip), so that finalize does not have to read the planes once more just to add them up.
@@ -152,568 +175,512 @@ __device__ __forceinline__ void seg_add(const CountTables& T, uint32_t dir, uint
 // (CountTables.dirty: the line of plane position c of strand dir now holds something)
 __device__ __forceinline__ void mark_dirty(const CountTables& T, uint32_t dir, uint64_t c) { T.dirty[((c >> 4) << 1) + dir] = 1; }
 
-__device__ __forceinline__ uint64_t plane_of(const CountTables& T, uint32_t m, uint64_t g) {
-    if (!T.pmap) return g;
-    const uint64_t c = (uint64_t)(m >> 1) << kBucketShift;
-    return (m & 1u) ? c + (g & ((1u << kBucketShift) - 1u)) : c;
-}
-
-// A difference event outside the chunk's window: the line cache, else (line slot taken by another line) a global atomic.
-__device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use_win, uint64_t c, uint32_t dir, int v) {
-#ifdef K_NOLINES
-    __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    seg_add(T, dir, c, v);
-    mark_dirty(T, dir, c);
-    return;
-#endif
-    // (a line holds both strands, packed like the window: unstranded reads put both on the same positions, so this is
-    //  twice the lines for the same LDS; the packed halves cannot overflow while use_win holds)
-    // (one compare-and-swap claims an empty slot or returns the line that holds it: no read + branch in front of it; the
-    //  counter update is predicated like the window's — line kLines is nobody's — so only a conflict is a branch)
-    const uint32_t want = (uint32_t)(c >> 4);
+// A difference event outside the window, at plane position (p5 << 5) + sub: the line cache, else (line slot taken by
+// another line, or the chunk bypasses the packed accumulators) a global atomic.
+__device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use_win, uint32_t p5, uint32_t sub, uint32_t dir, int v) {
+    // (a line holds both strands, packed like the window: unstranded reads put both on the same positions; one
+    //  compare-and-swap claims an empty slot or returns the line that holds it; the counter update is predicated like the
+    //  window's — line kLines is nobody's — so only a conflict is a branch)
+    const uint32_t want = (p5 << 1) | (sub >> 4);
     const uint32_t slot = want & (kLines - 1u);
-    const uint32_t old = atomicCAS(&S.ltag[slot], kEmpty, want);
+    uint32_t old = want + 1u;
+    if (use_win) old = atomicCAS(&S.ltag[slot], kEmpty, want);
     const bool mine = use_win && (old == kEmpty || old == want);
-    atomicAdd(&S.lcnt[mine ? slot : kLines][c & 15u], mine ? (dir ? v * 65536 : v) : 0);
+    atomicAdd(&S.lcnt[mine ? slot : kLines][sub & 15u], mine ? (dir ? v * 65536 : v) : 0);
     if (!mine) {
+        const uint64_t c = ((uint64_t)p5 << 5) + sub;
         __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seg_add(T, dir, c, v);
         mark_dirty(T, dir, c);
     }
 }
 
-// One difference event at plane position c, with a predicate instead of a branch around the call: the chunk's LDS window if
-// it is inside, else far_event.  The window update is executed by every lane (lanes
-// without an event, or with a far one, add 0 to a cell of their own behind the window), so that only the far path is a
-// branch — the kernel is bound by instruction issue, and the exec-mask bookkeeping of a branch costs as much as the update.
-__device__ __forceinline__ void depth_event_p(const CountTables& T, Lds& S, unsigned long long win, bool use_win, uint64_t c,
-                                              uint32_t dir, int v, bool pred, uint32_t& wmax) {
-    const uint64_t o = c - win;
-    const bool near = pred && use_win && o < kWin;
-    const uint32_t idx = near ? (uint32_t)o : kWin + (threadIdx.x & 63u);
+// One difference event with a predicate instead of a branch around the call.  w = the plane word of the position's cell
+// (kernels.h: cell tables), sub = position & 31.  Inside the window [win5 << 5, + kWin): one LDS add to the circular
+// window; the update is executed by every lane (lanes without an event, or with a far one, add 0 to a cell of their own
+// behind the window), so that only the far path is a branch.
+__device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, uint32_t win5, bool use_win, uint32_t w, uint32_t sub, uint32_t dir, int v,
+                                            bool pred, uint32_t lane, uint32_t& wmax) {
+    const uint32_t p5 = w & 0x7fffffffu;
+    const uint32_t subk = sub & (uint32_t)((int32_t)w >> 31);          // a cell that is not kept maps, whole, to one position
+    const uint32_t rel5 = p5 - win5;
+    const bool near = pred && use_win && rel5 < (kWin >> 5);
+    const uint32_t idx = near ? (((p5 << 5) & (kWin - 1u)) | subk) : kWin + lane;
     atomicAdd(&S.tile[idx], near ? (dir ? v * 65536 : v) : 0);
-    const uint32_t om = near ? (uint32_t)o : 0u;
-    wmax = om > wmax ? om : wmax;
-    if (pred && !near) far_event(T, S, use_win, c, dir, v);
+    const uint32_t top = near ? ((rel5 << 5) | subk) + 1u : 0u;
+    wmax = top > wmax ? top : wmax;
+    if (pred && !near) far_event(T, S, use_win, p5, subk, dir, v);
 }
 
-// n reads of strand dir on known junction idx: the chunk's LDS counter, or (slot taken by another junction) straight to
-// the table.  The counter also stands for the reads' two difference events next to the junction: they are applied once
-// per junction and sample by known_junction_depth_kernel at finalize, not once per read (or per chunk) here.
-__device__ __forceinline__ void junction_add(const CountTables& T, Lds& S, uint32_t idx, uint32_t dir, uint32_t n) {
-    const uint32_t slot = idx & (kJCache - 1u);
+// One read of strand dir on the known junction of row `row`: the LDS counter, or (slot taken by another junction) straight
+// to the table.  The counter also stands for the read's two difference events next to the junction: they are applied once
+// per junction and sample by known_junction_depth_kernel at finalize.
+__device__ __forceinline__ void junction_add(const CountTables& T, Lds& S, uint32_t row, uint32_t dir) {
+    const uint32_t slot = row & (kJCache - 1u);
     uint32_t tag = S.jtag[slot];
     if (tag == kEmpty) {
-        const uint32_t old = atomicCAS(&S.jtag[slot], kEmpty, idx);
-        tag = old == kEmpty ? idx : old;
+        const uint32_t old = atomicCAS(&S.jtag[slot], kEmpty, row);
+        tag = old == kEmpty ? row : old;
     }
-    if (tag == idx) atomicAdd(&S.jcnt[dir][slot], n);
-    else atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + T.known_kjidx[idx]], n);
+    if (tag == row) atomicAdd(&S.jcnt[dir][slot], 1u);
+    else atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + row], 1u);
 }
 
-__global__ __launch_bounds__(kThreads, K_MIN_WGS) void count_kernel(CountTables T, BatchDev B) {
-    __shared__ __align__(16) Lds S;
-    const uint32_t tid = threadIdx.x;
-    for (int k = tid; k < kChrBins; k += kThreads) S.chr[k] = 0;
-    for (int k = tid; k < (int)kWin + 64; k += kThreads) S.tile[k] = 0;
-    for (int k = tid; k < (int)kLines; k += kThreads) S.ltag[k] = kEmpty;
-    for (int k = tid; k < (int)(kLines + 1) * 16; k += kThreads) S.lcnt[k >> 4][k & 15] = 0;
-    for (int k = tid; k < (int)kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
-    for (int k = tid; k < (int)kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
-    for (int k = tid; k < (int)kNovelH; k += kThreads) { S.nh_key[k] = kEmpty64; S.nh_cnt[k] = 0; }
-    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.wmax = 0; }
-    __syncthreads();
+__device__ __forceinline__ void point_add(const CountTables& T, Lds& S, uint32_t pi, uint32_t dir) {
+    const uint32_t slot = pi & (kPCache - 1u);
+    uint32_t tag = S.ptag[slot];
+    if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ptag[slot], kEmpty, pi); tag = old == kEmpty ? pi : old; }
+    if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
+    else atomicAdd(&T.sp_cnt[(uint64_t)dir * T.n_sp + T.sp_row[pi]], 1u);
+}
 
-    const uint32_t lane = tid & 63u;
+// A read on a novel junction: a packed event for the sort-reduce at finalize.  A slice sits on one locus, so its novel events
+// repeat a handful of keys: they are merged in an LDS table and leave as (key, weight).
+__device__ __forceinline__ void novel_add(const CountTables& T, Lds& S, unsigned long long ev, uint32_t lane, uint32_t& err) {
+    const uint32_t h = (uint32_t)((ev * 0x9E3779B97F4A7C15ull) >> 57);
+    bool merged = false;
+#pragma unroll
+    for (uint32_t pr = 0; pr < 4u; pr++) {
+        if (merged) continue;
+        const uint32_t sl = (h + pr) & (kNovelH - 1u);
+        unsigned long long cur = S.nh_key[sl];
+        if (cur == kEmpty64) {
+            const unsigned long long old = atomicCAS(&S.nh_key[sl], kEmpty64, ev);
+            cur = old == kEmpty64 ? ev : old;
+            if (old == kEmpty64) atomicAdd(&S.nh_n, 1u);
+        }
+        if (cur == ev) { atomicAdd(&S.nh_cnt[sl], 1u); merged = true; }
+    }
+    if (!merged) {
+        const uint32_t q = atomicAdd(&S.nq_n, 1u);
+        if (q < kNovelQ) {
+            S.nq[q] = ev;
+        } else {
+            // table and queue full (a run without ref-sj.ref over a dense locus): the lanes that got here reserve slots together
+            const uint64_t m = __ballot(1);
+            const int lead = __ffsll((long long)m) - 1;
+            unsigned long long b = 0;
+            if ((int)lane == lead) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
+            b = __shfl(b, lead);
+            const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < T.junc_capacity) { T.junc_keys[slot] = ev; T.junc_w[slot] = 1u; } else err |= ERR_JUNC_CAPACITY;
+        }
+    }
+}
+
+// Window cells of the positions win + [0, to): one global atomic per non-zero cell and strand, consecutive lanes =
+// consecutive positions (whole 64-byte lines for the memory-side atomic unit); the cells are left zero.
+__device__ __forceinline__ void flush_window(const CountTables& T, Lds& S, unsigned long long win, uint32_t to, uint32_t lane, uint32_t wave) {
+    for (uint32_t g = wave * 64u; g < to; g += kWaves * 64u) {
+        const uint64_t p = win + g + lane;                              // (win and g are multiples of 64: one segment per wave)
+        const uint32_t idx = (uint32_t)p & (kWin - 1u);
+        const int32_t v = S.tile[idx];
+#ifndef K_NO_SKIP
+        if (__ballot(v != 0) == 0ull) continue;                         // (nothing in these 64 positions)
+#endif
+        const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
+        const int32_t v1 = (v - v0) >> 16;
+        if (v) {
+#ifndef K_DIAG_NO_FLUSH_ATOMICS
+            int32_t* d = T.diff + p;
+            if (v0) __hip_atomic_fetch_add(d, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v1) __hip_atomic_fetch_add(d + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            S.tile[idx] = 0;
+        }
+        // (the two strands' sums in one pass: the packed halves of a sum cannot overflow, see kEvFlush)
+        const int32_t sp = wave_sum_dpp(v);
+        const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
+        if (lane == 63u) {
+#ifndef K_DIAG_NO_FLUSH_ATOMICS
+            if (s0) seg_add(T, 0u, p, s0);
+            if (s1) seg_add(T, 1u, p, s1);
+#endif
+            // the wave's four lines, both strands: eight consecutive marks
+            *reinterpret_cast<unsigned long long*>(T.dirty + ((p >> 6) << 3)) = 0x0101010101010101ull;
+        }
+    }
+}
+
+// Far-line cache, junction counters, point counters, novel junctions -> the tables; all left empty.
+__device__ __forceinline__ void flush_caches(const CountTables& T, Lds& S, uint32_t tid, uint32_t lane, uint32_t wave, uint32_t& err) {
+    for (uint32_t e = tid; e < kLines * 16u; e += kThreads) {
+        const uint32_t slot = e >> 4, cell = e & 15u;               // a 16-lane row = one line = inside one segment
+        const uint32_t tag = S.ltag[slot];
+#ifndef K_NO_SKIP
+        if (__ballot(tag != kEmpty) == 0ull) continue;              // (none of the wave's four lines is claimed)
+#endif
+        const int32_t v = tag != kEmpty ? S.lcnt[slot][cell] : 0;
+        const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
+        const int32_t v1 = (v - v0) >> 16;
+        const uint64_t c = ((uint64_t)tag << 4) + cell;
+        if (v) {
+#ifndef K_DIAG_NO_FLUSH_ATOMICS
+            if (v0) __hip_atomic_fetch_add(T.diff + c, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v1) __hip_atomic_fetch_add(T.diff + T.plane_stride + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            S.lcnt[slot][cell] = 0;
+        }
+        const int32_t sp = row_sum_dpp(v);
+        const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
+        if (cell == 15u && tag != kEmpty) {
+#ifndef K_DIAG_NO_FLUSH_ATOMICS
+            if (s0) seg_add(T, 0u, c, s0);
+            if (s1) seg_add(T, 1u, c, s1);
+#endif
+            // (a claimed line is marked for both strands whatever it holds: marking too much only costs the clear a line)
+            *reinterpret_cast<uint16_t*>(T.dirty + ((uint64_t)tag << 1)) = 0x0101u;
+            S.ltag[slot] = kEmpty;          // (the row's 16 lanes have read the tag: same wave, program order)
+        }
+    }
+    for (uint32_t e = tid; e < kJCache; e += kThreads) {
+        const uint32_t row = S.jtag[e];
+        if (row != kEmpty) {
+            const uint32_t c0 = S.jcnt[0][e], c1 = S.jcnt[1][e];
+#ifndef K_DIAG_NO_FLUSH_ATOMICS
+            if (c0) atomicAdd(&T.known_cnt[row], c0);
+            if (c1) atomicAdd(&T.known_cnt[(uint64_t)T.n_kj + row], c1);
+#endif
+            S.jtag[e] = kEmpty; S.jcnt[0][e] = 0; S.jcnt[1][e] = 0;
+        }
+    }
+    for (uint32_t e = tid; e < kPCache; e += kThreads) {
+        const uint32_t pi = S.ptag[e];
+        if (pi != kEmpty) {
+            const uint32_t c0 = S.pcnt[0][e], c1 = S.pcnt[1][e];
+            const uint32_t row = T.sp_row[pi];
+            if (c0) atomicAdd(&T.sp_cnt[row], c0);
+            if (c1) atomicAdd(&T.sp_cnt[(uint64_t)T.n_sp + row], c1);
+            S.ptag[e] = kEmpty; S.pcnt[0][e] = 0; S.pcnt[1][e] = 0;
+        }
+    }
+    if (wave == 0u) {
+        // records of the slice so far: the merged table first (compacted with ballots), then the queue (weight 1)
+        const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ, nh = S.nh_n;
+        if (nq + nh) {
+            unsigned long long qb = 0;
+            if (lane == 0u) qb = atomicAdd(T.junc_count, (unsigned long long)(nq + nh));
+            qb = __shfl(qb, 0);
+            uint32_t at = 0;
+#pragma unroll
+            for (uint32_t e0 = 0; e0 < kNovelH; e0 += 64u) {
+                const unsigned long long k = S.nh_key[e0 + lane];
+                const uint32_t w = S.nh_cnt[e0 + lane];
+                const uint64_t occ = __ballot(k != kEmpty64);
+                if (k != kEmpty64) {
+                    const unsigned long long slot = qb + at + (unsigned long long)__popcll(occ & ((1ull << lane) - 1ull));
+                    if (slot < T.junc_capacity) { T.junc_keys[slot] = k; T.junc_w[slot] = w; } else err |= ERR_JUNC_CAPACITY;
+                    S.nh_key[e0 + lane] = kEmpty64; S.nh_cnt[e0 + lane] = 0;
+                }
+                at += (uint32_t)__popcll(occ);
+            }
+            for (uint32_t e = lane; e < nq; e += 64u) {
+                if (qb + nh + e < T.junc_capacity) { T.junc_keys[qb + nh + e] = S.nq[e]; T.junc_w[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
+            }
+            if (lane == 0u) { S.nq_n = 0; S.nh_n = 0; }
+        }
+    }
+}
+
+// Where every chunk puts its window: the plane position, rounded down to 64, of the start of its first fragment; kNoWin: that
+// fragment says nothing (not counted, outside its chromosome).  A kernel of its own in front of the count kernel, so that
+// no wave of the count kernel walks this chain of three dependent loads while its workgroup waits.
+__global__ __launch_bounds__(256) void chunk_origin_kernel(CountTables T, BatchDev B, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t f = c * kChunk;
+    unsigned long long o = kNoWin;
+    const uint32_t chr = B.frag_chr[f], fs = B.frag_start[f];
+    if (chr < T.n_chr) {
+        const uint4 rec = T.chr_rec[chr];
+        if (rec.w && fs <= rec.z) {
+            const uint64_t g = ((uint64_t)rec.y << 32 | rec.x) + fs;
+            const uint32_t w = T.cell_s[g >> kCellShift].z;
+            const uint64_t p = ((uint64_t)(w & 0x7fffffffu) << 5) + ((w >> 31) ? (uint32_t)g & 31u : 0u);
+            o = p & ~63ull;
+        }
+    }
+    T.chunk_origin[c] = o;
+}
+
+__global__ __launch_bounds__(kThreads, K_WGS_PER_CU) void count_kernel(CountTables T, BatchDev B) {
+    __shared__ __align__(16) Lds S;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t k = tid; k < kChrBins; k += kThreads) S.chr[k] = 0;
+    for (uint32_t k = tid; k < kWin + 64u; k += kThreads) S.tile[k] = 0;
+    for (uint32_t k = tid; k < kLines; k += kThreads) S.ltag[k] = kEmpty;
+    for (uint32_t k = tid; k < (kLines + 1u) * 16u; k += kThreads) S.lcnt[k >> 4][k & 15u] = 0;
+    for (uint32_t k = tid; k < kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
+    for (uint32_t k = tid; k < kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
+    for (uint32_t k = tid; k < kNovelH; k += kThreads) { S.nh_key[k] = kEmpty64; S.nh_cnt[k] = 0; }
+    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.wmax[0] = 0; S.wmax[1] = 0; }
+
     uint32_t err = 0;
 #ifdef COUNT_PROF
     unsigned long long prof_t = wall_clock64();
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
-    const U32V* __restrict__ chr4 = reinterpret_cast<const U32V*>(B.frag_chr);
-    const U32V* __restrict__ fs4 = reinterpret_cast<const U32V*>(B.frag_start);
-    const U32V* __restrict__ fe4 = reinterpret_cast<const U32V*>(B.frag_end);
-    const U32V* __restrict__ off4 = reinterpret_cast<const U32V*>(B.frag_blk_off);
-    const U8V* __restrict__ flg4 = reinterpret_cast<const U8V*>(B.frag_flags);
-    const U32V* __restrict__ bs4 = reinterpret_cast<const U32V*>(B.blk_start);
-    const U32V* __restrict__ bl4 = reinterpret_cast<const U32V*>(B.blk_len);
-    const U8V* __restrict__ rd4 = reinterpret_cast<const U8V*>(B.blk_read);
-    // XCD-aware chunk order: workgroup b runs on XCD b % 8 (round-robin dispatch); every XCD gets a contiguous
-    // eighth of the (coordinate-sorted) batch, so that neighbouring chunks — same table lines, overlapping
-    // difference windows — share one L2
-    const uint32_t xcd = blockIdx.x & 7u, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
-    const uint32_t per_xcd = (n_chunks + 7u) / 8u;
-    const uint32_t c_end = (xcd + 1u) * per_xcd < n_chunks ? (xcd + 1u) * per_xcd : n_chunks;
-#ifdef K_INTERLEAVE
-    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-#else
-    for (uint32_t c = xcd * per_xcd + wg_in_xcd; c < c_end; c += wgs_per_xcd) {
+    const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
+    const uint32_t n_slices = (n_chunks + kSlice - 1u) / kSlice;
+    // the columns of a chunk's fragments and the chunk's block range: loaded one chunk ahead, under the block phase
+    struct FragCols { uint32_t chr, fs, fe, o0, o1, flg, kb0, kb1; };
+    auto load_frag = [&](uint32_t c) -> FragCols {
+        FragCols r;
+        const uint32_t f0 = c * kChunk, f = f0 + tid;
+        const uint32_t fc = f < B.n_frag ? f : B.n_frag - 1u;
+        r.chr = B.frag_chr[fc]; r.fs = B.frag_start[fc]; r.fe = B.frag_end[fc];
+        r.o0 = B.frag_blk_off[fc]; r.o1 = B.frag_blk_off[fc + 1u]; r.flg = B.frag_flags[fc];
+        const uint32_t f_end = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
+        r.kb0 = B.frag_blk_off[f0]; r.kb1 = B.frag_blk_off[f_end];
+        return r;
+    };
+    for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        const uint32_t c0 = slice * kSlice;
+        const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
+        unsigned long long win = 0;     // window = plane positions [win, win + kWin); uniform over the workgroup, like the next three
+        uint32_t wtop = 0;              // cells of win + [0, wtop) may be non-zero
+        uint32_t ev_since = 0;          // upper bound of the events added since everything was last flushed
+        uint32_t since_flush = 0;       // chunks since the caches were last flushed
+        FragCols fc_next = load_frag(c0);
+#ifdef K_SLICE_BARRIER
+        wg_barrier();
 #endif
-        const uint32_t f0 = c * kChunk;
-        // ---------------- 1. fragment-parallel: fragments f0 + 4 tid .. + 3 ----------------
-        {
-            // a 16-byte group that starts inside an array never leaves the array's last page: lanes past the end read
-            // the last group again and discard it
-            const uint32_t g_last = (B.n_frag - 1u) >> kVecLog2;
-            const uint32_t g = (f0 >> kVecLog2) + tid < g_last ? (f0 >> kVecLog2) + tid : g_last;
-            const U32V vchr = chr4[g], vfs = fs4[g], vfe = fe4[g], voff = off4[g];
-            const uint32_t vflg = flg4[g];
-            if (tid == 0) {
-                const uint32_t last = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
-                const uint32_t o = B.frag_blk_off[last];
-                S.off[kChunk] = o < B.n_blk ? o : B.n_blk;
-            }
-            uint32_t chr[kVec], fs[kVec], fe[kVec], off[kVec];
-            unpack(vchr, chr); unpack(vfs, fs); unpack(vfe, fe); unpack(voff, off);
-            uint32_t key[kVec], clen[kVec];
-            uint64_t base[kVec];
-            bool in[kVec];
-#pragma unroll
-            for (int j = 0; j < kVec; j++) {
-                const uint32_t i = f0 + tid * kVec + j;
-                in[j] = i < B.n_frag;
-                const bool ok = in[j] && chr[j] < T.n_chr;
-                if (in[j] && !ok) err |= ERR_CHR_RANGE;
-                // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here):
-                // inside the array's bounds, non-decreasing inside the lane's group (across groups: after the barrier)
-                if (in[j] && (off[j] > B.n_blk || (j > 0 && off[j] < off[j - 1]) || (i == 0u && off[j] != 0u))) err |= ERR_CSR;
-                const uint32_t cc = ok ? chr[j] : 0u;            // the tables hold at least one entry
-                const bool counted = (T.chr_owned[cc] != 0) && ok;
-                base[j] = T.chr_base[cc];
-                clen[j] = T.chr_len[cc];
-                if (!counted) { base[j] = 0ull; clen[j] = 0u; }
-                const uint32_t dir = (vflg >> (8 * j)) & 1u;
-                const uint32_t li = tid * kVec + j;
-                S.off[li] = in[j] ? (off[j] < B.n_blk ? off[j] : B.n_blk) : B.n_blk;
-                S.fb[li] = counted ? ((uint32_t)(base[j] >> 6) | (dir ? kFragDir : 0u) | kFragValid) : 0u;
-                S.fclen[li] = clen[j];
-                key[j] = counted ? chr[j] * 2u + dir : kEmpty;
-            }
-            if (tid == 0) {
-                // the window starts at the chunk's first fragment (coordinate-sorted input: the leftmost one)
-                unsigned long long w = 0;
-                if (key[0] != kEmpty && fs[0] <= clen[0]) {
-                    const uint64_t gp = base[0] + fs[0];
-                    w = plane_of(T, T.pmap ? T.pmap[gp >> kBucketShift] : 0u, gp) & ~63ull;
+        for (uint32_t i = 0; i <= nc; i++) {
+            CPROF(5);
+            wg_barrier();            // ---- the block phase of chunk i - 1 is over (i = 0: the LDS is initialised / flushed) ----
+            CPROF(0);
+            wtop = umax(wtop, S.wmax[(i + 1u) & 1u]);
+#ifdef K_DIAG_FULL_WTOP
+            wtop = kWin;
+#endif
+            const bool last = i == nc;
+            const unsigned long long nw = last ? kNoWin : T.chunk_origin[c0 + i];
+            if (tid == 0) S.wmax[i & 1u] = 0;
+
+            // ---------------- the window follows the chunks; the caches are flushed every few chunks ----------------
+            {
+                const bool ev_full = ev_since > kEvFlush;
+                bool jump = false;
+                uint32_t scroll = 0;
+                if (nw != kNoWin) {
+                    if (nw < win || nw - win >= kWin) jump = true; else scroll = (uint32_t)(nw - win);
                 }
-                S.win = w;
+                if (last || ev_full || jump) {
+                    flush_window(T, S, win, wtop, lane, wave);
+                    wtop = 0;
+                } else if (scroll) {
+                    flush_window(T, S, win, scroll < wtop ? scroll : wtop, lane, wave);
+                    wtop = wtop > scroll ? wtop - scroll : 0u;
+                }
+                if (nw != kNoWin) win = nw;
+                since_flush++;
+                if (last || ev_full || since_flush >= kFlushEvery) {
+                    flush_caches(T, S, tid, lane, wave, err);
+                    since_flush = 0;
+                }
+                if (last || ev_full) ev_since = 0;
             }
+            CPROF(1);
+            if (last) break;            // (the slice's accumulators are empty again)
+
+            // ---------------- F. fragment phase of chunk i ----------------
+            const uint32_t f0 = (c0 + i) * kChunk, f = f0 + tid;
+            const bool in = f < B.n_frag;
+            const uint32_t chr = fc_next.chr, fs = fc_next.fs, fe = fc_next.fe, o0 = fc_next.o0, o1 = fc_next.o1, flg = fc_next.flg;
+            uint32_t kb0 = fc_next.kb0, kb1 = fc_next.kb1;
+            // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here): inside
+            // the array's bounds, non-decreasing, spanning [0, n_blk].  Clamped, they address nothing out of bounds.
+            if (in && (o0 > B.n_blk || o1 > B.n_blk || o1 < o0 || (f == 0u && o0 != 0u) || (f == B.n_frag - 1u && o1 != B.n_blk))) err |= ERR_CSR;
+            kb0 = kb0 < B.n_blk ? kb0 : B.n_blk;
+            kb1 = kb1 < B.n_blk ? kb1 : B.n_blk;
+            if (kb1 < kb0) kb1 = kb0;
+            uint32_t o0c = o0 < B.n_blk ? o0 : B.n_blk, o1c = o1 < B.n_blk ? o1 : B.n_blk;
+            if (!in) { o0c = 0; o1c = 0; }
+            const bool chr_ok = in && chr < T.n_chr;
+            if (in && !chr_ok) err |= ERR_CHR_RANGE;
+            const uint4 rec = T.chr_rec[chr_ok ? chr : 0u];                // the table holds at least one entry
+            const bool counted = chr_ok && rec.w != 0u;
+            const uint64_t base = (uint64_t)rec.y << 32 | rec.x;
+            const uint32_t clen = rec.z;
+            const uint32_t dir = flg & 1u;
+            S.facts[tid] = counted ? make_uint2((uint32_t)(base >> 6) | (dir ? kFragDir : 0u) | kFragValid, clen) : make_uint2(0u, 0u);
+            // the owner entries of the fragment's blocks (first tile; the others below)
+            auto scatter = [&](uint32_t t0) {
+                for (uint32_t k = o0c > t0 ? o0c : t0; k < o1c && k - t0 <= kTile; k++)
+                    S.owner[k - t0] = (uint16_t)(tid | (k == o0c ? kOwnFirst : 0u) | (k + 1u == o1c ? kOwnLast : 0u));
+            };
+            scatter(kb0);
             // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
-            if (!(T.ablate & 4u) && T.n_roi_dev) {
-                uint32_t r[kVec];
-                bool extent_ok[kVec];
-#pragma unroll
-                for (int j = 0; j < kVec; j++) {
-                    extent_ok[j] = key[j] != kEmpty && fs[j] <= fe[j] && fe[j] <= clen[j];
-                    r[j] = T.roi_bucket[extent_ok[j] ? (base[j] + fe[j]) >> kBucketShift : 0ull];
-                }
-                uint64_t rge[kVec], rgs[kVec];
-#pragma unroll
-                for (int j = 0; j < kVec; j++) {
-                    if (r[j] >= T.n_roi_dev) { extent_ok[j] = false; r[j] = 0u; }
-                    rge[j] = T.roi_gend[r[j]];
-                    rgs[j] = T.roi_gstart[r[j]];
-                }
-#pragma unroll
-                for (int j = 0; j < kVec; j++) {
-                    if (!extent_ok[j]) continue;
-                    const uint64_t gfs = base[j] + fs[j], gfe = base[j] + fe[j];
-                    uint32_t q = r[j];
-                    if (rge[j] < gfe) {          // several ROIs end inside the bucket before the fragment does
+            if (T.n_roi_dev) {
+                const bool extent_ok = counted && fs <= fe && fe <= clen;
+                const uint64_t gfs = base + fs, gfe = base + fe;
+                const uint4 R = T.roi_bkt[extent_ok ? gfe >> kBucketShift : 0ull];
+                if (extent_ok && R.x < T.n_roi_dev) {
+                    uint32_t q = R.x;
+                    uint64_t rgs = (uint64_t)(R.w & 0xffffu) << 32 | R.y;
+                    const uint64_t rge = (uint64_t)(R.w >> 16) << 32 | R.z;
+                    bool have = true;
+                    if (rge < gfe) {              // several ROIs end inside the bucket before the fragment does
                         q++;
                         while (q < T.n_roi_dev && T.roi_gend[q] < gfe) q++;
-                        if (q >= T.n_roi_dev) continue;
-                        rgs[j] = T.roi_gstart[q];
+                        have = q < T.n_roi_dev;
+                        if (have) rgs = T.roi_gstart[q];
                     }
-                    if (rgs[j] <= gfs) atomicAdd(&T.roi_cnt[(uint64_t)(key[j] & 1u) * T.n_roi + T.roi_idx[q]], 1u);
+#ifndef K_DIAG_NO_ROI_ATOMICS
+                    if (have && rgs <= gfs) atomicAdd(&T.roi_cnt[(uint64_t)dir * T.n_roi + T.roi_idx[q]], 1u);
+#endif
                 }
             }
             // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
-            if (!(T.ablate & 16u)) {
-#pragma unroll
-                for (int j = 0; j < kVec; j++) {
-                    const uint32_t k = key[j];
-                    uint64_t todo = __ballot(k != kEmpty);
-                    while (todo) {
-                        const int lead = __ffsll((long long)todo) - 1;
-                        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)k, lead);
-                        const uint64_t same = __ballot(k == lk);
-                        if ((int)lane == lead) {
-                            const uint32_t n = (uint32_t)__popcll(same);
-                            if (lk < (uint32_t)kChrBins) atomicAdd(&S.chr[lk], n);
-                            else atomicAdd(&T.chr_cnt[lk], n);
-                        }
-                        todo &= ~same;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        CPROF(0);
-
-        // ---------------- 2. block-parallel: 4 consecutive blocks per lane ----------------
-        const uint32_t kb0 = S.off[0], kb1 = S.off[kChunk];
-        // (S.off[kChunk] is the offset behind the chunk's last fragment: the next group's first, or frag_blk_off[n_frag])
-        if (S.off[tid * kVec + kVec - 1] > S.off[tid * kVec + kVec] && f0 + tid * kVec + kVec - 1 < B.n_frag) err |= ERR_CSR;
-        if (tid == 0 && f0 + kChunk >= B.n_frag && B.frag_blk_off[B.n_frag] != B.n_blk) err |= ERR_CSR;
-        const unsigned long long win = S.win;
-        const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
-        uint32_t wmax = 0;
-        const uint32_t g_lastb = B.n_blk ? (B.n_blk - 1u) >> kVecLog2 : 0u;
-        // The block columns of an iteration are loaded one iteration ahead (the loads of the first iteration are issued
-        // here, before anything waits): a round trip less on the chain columns -> bucket entries -> key / point tables.
-        // Every lane also loads the block after its four itself (the junction to the right of its last block).
-        struct BlkCols { U32V vbs, vbl; uint32_t vrd, nbs, nbl, nrd; };
-        auto load_cols = [&](uint32_t k0) -> BlkCols {
-            BlkCols c;
-            const uint32_t g = (k0 >> kVecLog2) < g_lastb ? (k0 >> kVecLog2) : g_lastb;
-            const uint32_t kn = k0 + kVec < B.n_blk ? k0 + kVec : (B.n_blk ? B.n_blk - 1u : 0u);
-            c.vbs = bs4[g]; c.vbl = bl4[g]; c.vrd = rd4[g];
-            c.nbs = B.blk_start[kn]; c.nbl = B.blk_len[kn]; c.nrd = B.blk_read[kn];
-            return c;
-        };
-        BlkCols nxt = load_cols((kb0 & ~(uint32_t)(kVec - 1)) + tid * kVec);
-        for (uint32_t ka = kb0 & ~(uint32_t)(kVec - 1); ka < kb1 && !(T.ablate & 32u); ka += kThreads * kVec) {
-            const uint32_t k0 = ka + tid * kVec;
-            const BlkCols cur = nxt;
-            nxt = load_cols(k0 + kThreads * kVec);
-            uint32_t bs[kVec + 1], bl[kVec + 1], rd[kVec + 1];
-            unpack(cur.vbs, bs); bs[kVec] = cur.nbs;
-            unpack(cur.vbl, bl); bl[kVec] = cur.nbl;
-#pragma unroll
-            for (int j = 0; j < kVec; j++) rd[j] = (cur.vrd >> (8 * j)) & 0xffu;
-            rd[kVec] = cur.nrd;
-            // owner = the last fragment of the chunk whose offset is <= k (empty fragments share an offset with
-            // their successor and are never picked): binary search for the first block, a short walk for the others
-            uint32_t fbv[kVec], clen[kVec];
-            bool act[kVec], first[kVec], next_same[kVec];
             {
-                uint32_t lo = 0, hi = kChunk;
-                const uint32_t kq = k0 < kb0 ? kb0 : k0;
-#pragma unroll
-                for (int s = 0; s < kChunkLog2; s++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (S.off[mid] <= kq) lo = mid; else hi = mid;
-                }
-                uint32_t f = lo;
-#pragma unroll
-                for (int j = 0; j < kVec; j++) {
-                    const uint32_t k = k0 + j;
-                    act[j] = k >= kb0 && k < kb1;
-                    if (act[j]) { while (S.off[f + 1] <= k) f++; }        // off[kChunk] = kb1 > k ends the walk
-                    fbv[j] = act[j] ? S.fb[f] : 0u;
-                    clen[j] = S.fclen[f];
-                    first[j] = k == S.off[f];
-                    next_same[j] = k + 1u < S.off[f + 1];
-                }
-            }
-            // per block: validity, full coordinates, bucket-table entries of the start and of the end
-            bool ok[kVec + 1];
-            uint64_t gbs[kVec + 1], gbe[kVec];
-            uint2 es[kVec + 1];
-            uint4 ee[kVec];
-#pragma unroll
-            for (int j = 0; j < kVec; j++) {
-                const uint32_t be = bs[j] + bl[j];
-                const bool valid = (fbv[j] & kFragValid) != 0u;
-                const bool in_range = be >= bs[j] && be <= clen[j];
-                if (valid && !in_range) err |= ERR_BLOCK_RANGE;
-                ok[j] = valid && in_range;
-                const uint64_t base = (uint64_t)(fbv[j] & kFragBaseMask) << 6;
-                gbs[j] = base + bs[j];
-                gbe[j] = base + be;
-            }
-            {   // the successor of the lane's last block: same fragment (next_same[3]) or unused
-                const uint32_t be = bs[kVec] + bl[kVec];
-                ok[kVec] = ok[kVec - 1] && next_same[kVec - 1] && be >= bs[kVec] && be <= clen[kVec - 1];
-                gbs[kVec] = ((uint64_t)(fbv[kVec - 1] & kFragBaseMask) << 6) + bs[kVec];
-            }
-#pragma unroll
-            for (int j = 0; j <= kVec; j++) {
-                const uint4* e = T.bkt + (ok[j] ? gbs[j] >> kBucketShift : 0ull);
-                es[j] = *reinterpret_cast<const uint2*>(e);
-            }
-#pragma unroll
-            for (int j = 0; j < kVec; j++) ee[j] = T.bkt[ok[j] ? gbe[j] >> kBucketShift : 0ull];
-            CPROF(1);
-            // junction to the right of the block: both flanks long enough, same read, same fragment
-            bool jc[kVec];
-            uint64_t jkey[kVec], kfirst[kVec];
-#pragma unroll
-            for (int j = 0; j < kVec; j++) {
-                jc[j] = ok[j] && ok[j + 1] && next_same[j] && rd[j + 1] == rd[j] && bl[j] >= T.junc_min_flank && bl[j + 1] >= T.junc_min_flank &&
-                        !(T.ablate & 8u);
-                const uint32_t be = bs[j] + bl[j];
-                const uint32_t span = bs[j + 1] - be;
-                if (jc[j] && (bs[j + 1] < be || span >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[j] = false; }
-                jkey[j] = (gbe[j] << kJuncSpanBits) | span;
-                const bool kq = jc[j] && (ee[j].w >> 16);
-                kfirst[j] = ~0ull;
-                if (kq) kfirst[j] = T.known_keys[ee[j].z];                    // (only the lanes with a candidate: see the SpansPoint load)
-            }
-            // SpansPoint: the first four points under every block are requested now, together with the junction keys
-            // (one round trip for all four blocks of the lane; points are compared modulo 2^32)
-            uint32_t sp_p[kVec], sp_p1[kVec], sp_g[kVec][4];
-            {
-#pragma unroll
-                for (int j = 0; j < kVec; j++) {
-                    const bool on = ok[j] && bl[j] > T.sp_min_len && !(T.ablate & 2u);
-                    sp_p[j] = es[j].y;
-                    sp_p1[j] = on ? ee[j].y + (ee[j].w & 0xffffu) : sp_p[j];      // saturated count: a lower bound, fixed below
-                    // ONE 16-byte load (dword-aligned; the table has four spare entries behind its end) and only by the lanes
-                    // that have candidates: the vector L1 handles about one lane's access per clock whatever its width,
-                    // and this kernel keeps it busy ~90 % of the time (profiles/r02q_count_pmc.txt)
-                    Quad q4 = {{0u, 0u, 0u, 0u}};
-                    if (sp_p[j] < sp_p1[j]) q4 = *reinterpret_cast<const Quad*>(T.sp_pos32 + sp_p[j]);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) sp_g[j][q] = q4.v[q];
-                }
-            }
-            // known junction?  (index into known_keys, or kEmpty)
-            uint32_t hit[kVec];
-#pragma unroll
-            for (int j = 0; j < kVec; j++) {
-                hit[j] = kEmpty;
-                const uint32_t kn = ee[j].w >> 16;
-                if (jc[j] && kn) {
-                    const uint32_t i0 = ee[j].z;
-                    if (kfirst[j] >= jkey[j]) {
-                        if (kfirst[j] == jkey[j]) hit[j] = i0;
-                    } else {
-                        uint32_t lo = i0 + 1u;
-                        uint32_t hi = kn == 0xffffu ? T.bkt[(gbe[j] >> kBucketShift) + 1u].z : i0 + kn;
-                        while (hi - lo > 4u) {        // many junctions share this donor bucket: bisect first
-                            const uint32_t mid = lo + ((hi - lo) >> 1);
-                            if (T.known_keys[mid] < jkey[j]) lo = mid + 1u; else hi = mid + 1u;
-                        }
-                        for (; lo < hi; lo++) {
-                            const uint64_t kq = T.known_keys[lo];
-                            if (kq >= jkey[j]) { if (kq == jkey[j]) hit[j] = lo; break; }
-                        }
+                const uint32_t k = counted ? chr * 2u + dir : kEmpty;
+                uint64_t todo = __ballot(k != kEmpty);
+                while (todo) {
+                    const int lead = __ffsll((long long)todo) - 1;
+                    const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)k, lead);
+                    const uint64_t same = __ballot(k == lk);
+                    if ((int)lane == lead) {
+                        const uint32_t n = (uint32_t)__popcll(same);
+                        if (lk < kChrBins) atomicAdd(&S.chr[lk], n);
+                        else atomicAdd(&T.chr_cnt[lk], n);
                     }
+                    todo &= ~same;
                 }
             }
+#ifndef K_NO_PREFETCH
+            if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);      // (in flight under the block phase)
+#ifdef K_PREFETCH_WAIT
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#endif
             CPROF(2);
-            // JunctionCount on known junctions: the junction's LDS counter (same-address LDS atomics of a wave are
-            // serialised by the hardware at about a lane per clock: cheaper than electing leaders in software).
-            // folded = the junction's counter also stands for this read's two difference events (applied at finalize)
-            bool folded[kVec];
-#pragma unroll
-            for (int j = 0; j < kVec; j++) {
-                folded[j] = hit[j] != kEmpty && !(T.ablate & 64u);
-                if (hit[j] != kEmpty) junction_add(T, S, hit[j], (fbv[j] & kFragDir) ? 1u : 0u, 1u);
-            }
+            wg_barrier();            // ---- facts and owners of chunk i are in place, the flushed cells are zero ----
             CPROF(3);
-            // difference events, SpansPoint, novel junctions
-            if (!(T.ablate & 1u)) {
-                // CoverageBlocks / FragmentsMap.  Every block end is one event site (unless a known junction's counter
-                // stands for it), every block start is one: of the lane's own first block only when it opens a fragment,
-                // of the others (the block after the lane's last included) when they open a fragment or follow a
-                // predecessor whose junction was not folded.  9 sites for 4 blocks, each with a predicate, not a branch.
-#pragma unroll
-                for (int j = 0; j < kVec; j++)
-                    depth_event_p(T, S, win, use_win, plane_of(T, ee[j].x, gbe[j]), (fbv[j] & kFragDir) ? 1u : 0u, -1, ok[j] && !folded[j], wmax);
-                depth_event_p(T, S, win, use_win, plane_of(T, es[0].x, gbs[0]), (fbv[0] & kFragDir) ? 1u : 0u, 1, ok[0] && first[0], wmax);
-#pragma unroll
-                for (int k = 1; k <= kVec; k++) {
-                    const bool opens = k < kVec && ok[k < kVec ? k : 0] && first[k < kVec ? k : 0];
-                    const bool follows = ok[k - 1] && !folded[k - 1] && next_same[k - 1] && ok[k];
-                    const uint32_t f = opens ? fbv[k < kVec ? k : 0] : fbv[k - 1];
-                    depth_event_p(T, S, win, use_win, plane_of(T, es[k].x, gbs[k]), (f & kFragDir) ? 1u : 0u, 1, opens || follows, wmax);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kVec; j++) {
-                if (!ok[j]) continue;
-                const uint32_t dir = (fbv[j] & kFragDir) ? 1u : 0u;
-                // SpansPoint: the points of the buckets under the block, filtered to [lo, hi].  The first four were
-                // requested above (they usually are the block's own exon boundaries, just outside [lo, hi], and the
-                // few points inside); more only for a block over a dense stretch
-                if (sp_p[j] < sp_p1[j]) {
-                    uint32_t p = sp_p[j];
-                    const uint32_t pn = ee[j].w & 0xffffu;
-                    const uint32_t p1 = pn == 0xffffu ? T.bkt[(gbe[j] >> kBucketShift) + 1u].y : sp_p1[j];
-                    const uint32_t lo = (uint32_t)gbs[j] + T.sp_lo_add, hi = (uint32_t)gbe[j] - T.sp_hi_sub;
-                    uint32_t* __restrict__ sp_cnt = T.sp_cnt + (uint64_t)dir * T.n_sp;
-                    auto point = [&](uint32_t pi) {
-                        const uint32_t slot = pi & (kPCache - 1u);
-                        uint32_t tag = S.ptag[slot];
-                        if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ptag[slot], kEmpty, pi); tag = old == kEmpty ? pi : old; }
-                        if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
-                        else atomicAdd(&sp_cnt[T.sp_row[pi]], 1u);
-                    };
-                    // which of the four requested candidates lie inside [lo, hi] (the points are sorted: the first one beyond
-                    // hi ends the search); the counter updates then run ONCE per qualifying point, not once per candidate
-                    bool done = false;
-                    uint32_t qual = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (p + q < p1 && !done) {
-                            const uint32_t g = sp_g[j][q];
-                            if ((int32_t)(g - hi) > 0) done = true;
-                            else if ((int32_t)(g - lo) >= 0) qual |= 1u << q;
-                        }
-                    }
-                    while (qual) {
-                        const uint32_t q = (uint32_t)__ffs((int)qual) - 1u;
-                        qual &= qual - 1u;
-                        point(p + q);
-                    }
-                    for (p += 4u; !done && p < p1; p++) {          // a block over a dense stretch of points (rare)
-                        const uint32_t g = T.sp_pos32[p];
-                        if ((int32_t)(g - hi) > 0) done = true;
-                        else if ((int32_t)(g - lo) >= 0) point(p);
-                    }
-                }
-                if (jc[j] && hit[j] == kEmpty) {
-                    // novel junction: a packed event for the sort-reduce at finalize.  A chunk sits on one locus, so its
-                    // novel events repeat a handful of keys: they are merged in an LDS table and leave as (key, weight)
-                    const uint64_t ev = (gbe[j] << kJuncLeftShift) | ((jkey[j] & ((1ull << kJuncSpanBits) - 1ull)) << 1) | dir;
-                    const uint32_t h = (uint32_t)((ev * 0x9E3779B97F4A7C15ull) >> 57);
-                    bool merged = false;
-#pragma unroll
-                    for (uint32_t pr = 0; pr < 4u; pr++) {
-                        if (merged) continue;
-                        const uint32_t sl = (h + pr) & (kNovelH - 1u);
-                        unsigned long long cur = S.nh_key[sl];
-                        if (cur == kEmpty64) {
-                            const unsigned long long old = atomicCAS(&S.nh_key[sl], kEmpty64, (unsigned long long)ev);
-                            cur = old == kEmpty64 ? (unsigned long long)ev : old;
-                            if (old == kEmpty64) atomicAdd(&S.nh_n, 1u);
-                        }
-                        if (cur == ev) { atomicAdd(&S.nh_cnt[sl], 1u); merged = true; }
-                    }
-                    if (!merged) {
-                        const uint32_t q = atomicAdd(&S.nq_n, 1u);
-                        if (q < kNovelQ) {
-                            S.nq[q] = ev;
-                        } else {
-                            // table and queue full (a run without ref-sj.ref over a dense locus): the lanes that got here reserve slots together
-                            const uint64_t m = __ballot(1);
-                            const int lead = __ffsll((long long)m) - 1;
-                            unsigned long long b = 0;
-                            if ((int)lane == lead) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
-                            b = __shfl(b, lead);
-                            const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                            if (slot < T.junc_capacity) { T.junc_keys[slot] = ev; T.junc_w[slot] = 1u; } else err |= ERR_JUNC_CAPACITY;
-                        }
-                    }
-                }
-            }
-            CPROF(7);
-        }
-        __syncthreads();
-        CPROF(4);
 
-        // ---------------- 3. flush the LDS accumulators ----------------
-        // 3a. the junction cache and the SpansPoint cache: counters to the tables
-        const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ;
-        const uint32_t nh = S.nh_n;
-        if (tid == 0 && nq + nh) S.nq_base = atomicAdd(T.junc_count, (unsigned long long)(nq + nh));
-        for (uint32_t e = tid; e < kJCache; e += kThreads) {
-            const uint32_t idx = S.jtag[e];
-            if (idx != kEmpty) {
-                const uint32_t c0 = S.jcnt[0][e], c1 = S.jcnt[1][e];
-                const uint32_t row = T.known_kjidx[idx];
-                if (c0) atomicAdd(&T.known_cnt[row], c0);
-                if (c1) atomicAdd(&T.known_cnt[(uint64_t)T.n_kj + row], c1);
-                S.jtag[e] = kEmpty; S.jcnt[0][e] = 0; S.jcnt[1][e] = 0;
-            }
-        }
-        for (uint32_t e = tid; e < kPCache; e += kThreads) {
-            const uint32_t pi = S.ptag[e];
-            if (pi != kEmpty) {
-                const uint32_t c0 = S.pcnt[0][e], c1 = S.pcnt[1][e];
-                const uint32_t row = T.sp_row[pi];
-                if (c0) atomicAdd(&T.sp_cnt[row], c0);
-                if (c1) atomicAdd(&T.sp_cnt[(uint64_t)T.n_sp + row], c1);
-                S.ptag[e] = kEmpty; S.pcnt[0][e] = 0; S.pcnt[1][e] = 0;
-            }
-        }
-        if (wmax) atomicMax(&S.wmax, wmax);
-        __syncthreads();
-        CPROF(5);
-        // 3b. line cache and window: consecutive lanes = consecutive positions, so that a wave's atomics fall into
-        //     whole 64-byte lines (the memory-side atomic unit works per line)
-        const uint32_t wtop = S.wmax;
-        static_assert((kLines * 16u) % kThreads == 0u && kWin % kThreads == 0u, "the flush loops run with whole waves (DPP sums)");
-        for (uint32_t e = tid; e < kLines * 16u; e += kThreads) {
-            const uint32_t slot = e >> 4, cell = e & 15u;               // a 16-lane row = one line = inside one segment
-            const uint32_t tag = S.ltag[slot];
-            const int32_t v = tag != kEmpty ? S.lcnt[slot][cell] : 0;
-            const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
-            const int32_t v1 = (v - v0) >> 16;
-            const uint64_t c = ((uint64_t)tag << 4) + cell;
-            if (v) {
-                if (v0 && !(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + c, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v1 && !(T.ablate & 256u)) __hip_atomic_fetch_add(T.diff + T.plane_stride + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                S.lcnt[slot][cell] = 0;
-            }
-            // (the two strands' sums in one pass: the packed halves of a sum cannot overflow while use_win holds, see far_event)
-            const int32_t sp = row_sum_dpp(v);
-            const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
-            if (cell == 15u && s0) seg_add(T, 0u, c, s0);
-            if (cell == 15u && s1) seg_add(T, 1u, c, s1);
-            // (a claimed line is marked for both strands whatever it holds: marking too much only costs the clear a line)
-            if (cell == 15u && tag != kEmpty) *reinterpret_cast<uint16_t*>(T.dirty + ((uint64_t)tag << 1)) = 0x0101u;
-        }
-        for (uint32_t e0 = 0; e0 <= wtop; e0 += kThreads) {
-            const uint32_t e = e0 + tid;                                // < kWin: the window is a multiple of the workgroup
-            const int32_t v = S.tile[e];
-            const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
-            const int32_t v1 = (v - v0) >> 16;
-            if (v) {
-                int32_t* g = T.diff + win + e;
-                if (v0 && !(T.ablate & 256u)) __hip_atomic_fetch_add(g, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v1 && !(T.ablate & 256u)) __hip_atomic_fetch_add(g + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                S.tile[e] = 0;
-            }
-            // the window starts on a multiple of 64: a wave's 64 positions share one segment
-            const int32_t sp = wave_sum_dpp(v);
-            const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
-            if (lane == 63u) {
-                if (s0) seg_add(T, 0u, win + e, s0);
-                if (s1) seg_add(T, 1u, win + e, s1);
-                // the wave's four lines, both strands: eight consecutive marks (the window starts on a multiple of 64)
-                *reinterpret_cast<unsigned long long*>(T.dirty + (((win + e) >> 6) << 3)) = 0x0101010101010101ull;
-            }
-        }
-        __syncthreads();
-        CPROF(6);
-        for (uint32_t e = tid; e < kLines; e += kThreads) S.ltag[e] = kEmpty;
-        if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.wmax = 0; }
-        if (nq + nh) {
-            // records of the chunk: the merged table first (wave 0 compacts it with ballots), then the queue (weight 1)
-            const unsigned long long qb = S.nq_base;
-            if (nh && tid < 64u) {
-                uint32_t at = 0;
+            // ---------------- B. block phase: one block per lane and stride of 63, kBU strides at once ----------------
+            const uint32_t nblk_c = kb1 - kb0;
+            const bool use_win = nblk_c <= kWinMaxBlocks;
+            if (use_win) ev_since += 2u * nblk_c;
+            const uint32_t win5 = (uint32_t)(win >> 5);
+            uint32_t wmax = 0;
+            struct Cols { uint32_t bs, bl, rd; };
+            auto load_cols = [&](uint32_t k) -> Cols {
+                const uint32_t kc = k < B.n_blk ? k : B.n_blk - 1u;      // (n_blk > 0 wherever this runs)
+                Cols c;
+                c.bs = B.blk_start[kc]; c.bl = B.blk_len[kc]; c.rd = B.blk_read[kc];
+                return c;
+            };
+            for (uint32_t t0 = kb0; t0 < kb1;) {
+                const uint32_t tile_n = kb1 - t0 < kTile ? kb1 - t0 : kTile;
+                const uint32_t n_str = (tile_n + kStride - 1u) / kStride;
+                for (uint32_t s0 = wave; s0 < n_str; s0 += kWaves * kBU) {
+                    // (a stride beyond the tile's last does nothing: `here` is false in every lane)
+                    Cols cur[kBU];
+                    uint32_t ti[kBU], ow[kBU], fb[kBU], clen_b[kBU], be[kBU], bdir[kBU];
+                    bool here[kBU], own[kBU], ok[kBU];
+                    uint4 rs[kBU], re[kBU], je[kBU];
 #pragma unroll
-                for (uint32_t e0 = 0; e0 < kNovelH; e0 += 64u) {
-                    const unsigned long long k = S.nh_key[e0 + tid];
-                    const uint32_t w = S.nh_cnt[e0 + tid];
-                    const uint64_t occ = __ballot(k != kEmpty64);
-                    if (k != kEmpty64) {
-                        const unsigned long long slot = qb + at + (unsigned long long)__popcll(occ & ((1ull << tid) - 1ull));
-                        if (slot < T.junc_capacity) { T.junc_keys[slot] = k; T.junc_w[slot] = w; } else err |= ERR_JUNC_CAPACITY;
-                        S.nh_key[e0 + tid] = kEmpty64; S.nh_cnt[e0 + tid] = 0;
+                    for (int u = 0; u < kBU; u++) {
+                        ti[u] = (s0 + u * kWaves) * kStride + lane;
+                        cur[u] = load_cols(t0 + ti[u]);
+                        here[u] = t0 + ti[u] < kb1 && ti[u] <= kTile;        // the block exists and has an owner entry in this tile
+                        own[u] = here[u] && lane < kStride && ti[u] < tile_n;
+                        ow[u] = S.owner[here[u] ? ti[u] : 0u];
                     }
-                    at += (uint32_t)__popcll(occ);
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        const uint2 fa = S.facts[ow[u] & 255u];
+                        fb[u] = here[u] ? fa.x : 0u; clen_b[u] = fa.y;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        const uint32_t bs = cur[u].bs;
+                        be[u] = bs + cur[u].bl;
+                        const bool in_range = be[u] >= bs && be[u] <= clen_b[u];
+                        const bool valid = (fb[u] & kFragValid) != 0u;
+                        if (own[u] && valid && !in_range) err |= ERR_BLOCK_RANGE;
+                        ok[u] = valid && in_range;
+                        bdir[u] = (fb[u] & kFragDir) ? 1u : 0u;
+                        const uint32_t cbase = (fb[u] & kFragBaseMask) << 1;      // base >> 5
+                        // the two cell records: plane coordinates of start and end, point ranks of both range ends
+                        rs[u] = T.cell_s[ok[u] ? cbase + (bs >> kCellShift) : 0u];
+                        re[u] = T.cell_e[ok[u] ? cbase + (be[u] >> kCellShift) : 0u];
+                    }
+                    uint32_t bs1[kBU], span[kBU], klo[kBU], khi[kBU], slot[kBU];
+                    uint64_t gbe[kBU];
+                    bool has_next[kBU], jc[kBU];
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        // the successor (next lane): junction to the right of the block — both flanks long enough, same read,
+                        // same fragment
+                        bs1[u] = from_next_lane(cur[u].bs);
+                        const uint32_t bl1 = from_next_lane(cur[u].bl), rd1 = from_next_lane(cur[u].rd);
+                        const bool ok1 = from_next_lane(ok[u] ? 1u : 0u) != 0u;
+                        has_next[u] = own[u] && ok[u] && !(ow[u] & kOwnLast) && ok1;
+                        jc[u] = has_next[u] && rd1 == cur[u].rd && cur[u].bl >= T.junc_min_flank && bl1 >= T.junc_min_flank;
+                        span[u] = bs1[u] - be[u];
+                        if (jc[u] && (bs1[u] < be[u] || span[u] >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[u] = false; }
+                        gbe[u] = ((uint64_t)(fb[u] & kFragBaseMask) << 6) + be[u];
+                        klo[u] = ((uint32_t)gbe[u] << kJuncSpanBits) | span[u];
+                        khi[u] = (uint32_t)(gbe[u] >> (32 - kJuncSpanBits));
+                        slot[u] = junction_hash(klo[u], khi[u]) & T.jh_mask;
+                        je[u] = T.jhash[jc[u] ? slot[u] : 0u];
+                        asm volatile("" : "+v"(je[u].z));       // (the row comes with the key, not in a second load behind the compare)
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        const uint32_t bs = cur[u].bs, bl = cur[u].bl;
+                        const uint32_t rsz1 = from_next_lane(rs[u].z);
+                        // known junction?  (the probe continues only past a slot another key holds: load <= 1/32)
+                        bool hit = jc[u] && je[u].x == klo[u] && je[u].y == khi[u];
+                        {
+                            bool more = jc[u] && !hit && (je[u].x & je[u].y) != kEmpty;
+                            while (more) {
+                                slot[u] = (slot[u] + 1u) & T.jh_mask;
+                                je[u] = T.jhash[slot[u]];
+                                hit = je[u].x == klo[u] && je[u].y == khi[u];
+                                more = !hit && (je[u].x & je[u].y) != kEmpty;
+                            }
+                        }
+                        // JunctionCount: a known junction's counter also stands for the read's two difference events here
+                        if (hit) junction_add(T, S, je[u].z, bdir[u]);
+                        if (jc[u] && !hit) novel_add(T, S, (gbe[u] << kJuncLeftShift) | ((unsigned long long)span[u] << 1) | bdir[u], lane, err);
+                        // CoverageBlocks / FragmentsMap: the block's end, its successor's start (unless the junction between
+                        // them was counted on a known junction), and its own start if it opens the fragment
+                        depth_event(T, S, win5, use_win, re[u].z, be[u] & 31u, bdir[u], -1, own[u] && ok[u] && !hit, lane, wmax);
+                        depth_event(T, S, win5, use_win, rsz1, bs1[u] & 31u, bdir[u], 1, has_next[u] && !hit, lane, wmax);
+                        depth_event(T, S, win5, use_win, rs[u].z, bs & 31u, bdir[u], 1, own[u] && ok[u] && (ow[u] & kOwnFirst) != 0u, lane, wmax);
+                        // SpansPoint: the points in [bs + sp_lo_add, be - sp_hi_sub] = ranks n0 .. n1 - 1
+                        if (own[u] && ok[u] && bl > T.sp_min_len) {
+                            const uint32_t n0 = rs[u].x + (uint32_t)__popc(rs[u].y & ((1u << (bs & 31u)) - 1u));
+                            const uint32_t n1 = re[u].x + (uint32_t)__popc(re[u].y & ((1u << (be[u] & 31u)) - 1u));
+                            for (uint32_t p = n0; p < n1; p++) point_add(T, S, p, bdir[u]);
+                        }
+                    }
+                }
+                t0 += kTile;
+                if (t0 < kb1) {         // a chunk with more blocks than one tile holds: the next tile's owners
+                    wg_barrier();
+                    scatter(t0);
+                    wg_barrier();
                 }
             }
-            for (uint32_t e = tid; e < nq; e += kThreads) {
-                if (qb + nh + e < T.junc_capacity) { T.junc_keys[qb + nh + e] = S.nq[e]; T.junc_w[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
-            }
+            wmax = wave_max_dpp(wmax);
+            if (lane == 63u && wmax) atomicMax(&S.wmax[i & 1u], wmax);
+#ifdef K_NO_PREFETCH
+            if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);
+#endif
+            CPROF(4);
         }
     }
 #ifdef COUNT_PROF
-    if (tid == 0 && blockIdx.x < 1024u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][k] = prof_acc[k];
+    if (lane == 0u && (wave == 0u || wave == 3u) && blockIdx.x < 2048u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][wave ? 1 : 0][k] = prof_acc[k];
 #endif
     if (err) atomicOr(T.err_flags, err);
-    __syncthreads();
-    for (int k = tid; k < kChrBins; k += kThreads) {
+    wg_barrier();
+    for (uint32_t k = tid; k < kChrBins; k += kThreads) {
         const uint32_t v = S.chr[k];
-        if (v && (uint32_t)(k >> 1) < T.n_chr) atomicAdd(&T.chr_cnt[k], v);
+        if (v && (k >> 1) < T.n_chr) atomicAdd(&T.chr_cnt[k], v);
     }
 }
 
@@ -736,7 +703,7 @@ __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T
         const uint32_t kd = T.known_dir[i];
         if (kd == 1u) { same += (uint32_t)cnt[0]; opp += (uint32_t)cnt[1]; }
         else if (kd == 2u) { same += (uint32_t)cnt[1]; opp += (uint32_t)cnt[0]; }
-        if ((T.ablate & (1u | 64u)) || !(cnt[0] | cnt[1])) continue;
+        if (!(cnt[0] | cnt[1])) continue;
         const uint64_t key = T.known_keys[i];
         const uint64_t gl = key >> kJuncSpanBits, gr = gl + (key & ((1ull << kJuncSpanBits) - 1ull));
         const uint64_t cl = plane_coord(T.pmap, gl), cr = plane_coord(T.pmap, gr);
@@ -792,7 +759,44 @@ __global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* __restrict__
     }
 }
 
+// The two cell tables (kernels.h).  One thread per cell: the rank of the cell's first shifted position among the sorted
+// points (binary search), the points of its 32 shifted positions as bits, and the plane word.
+__global__ __launch_bounds__(256) void build_cells_kernel(const uint64_t* __restrict__ points, uint32_t n_points, const uint32_t* __restrict__ pmap,
+                                                          uint64_t n_cells, int32_t shift_s, int32_t shift_e, uint4* __restrict__ cell_s,
+                                                          uint4* __restrict__ cell_e) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_cells) return;
+    uint32_t word;
+    if (pmap) {
+        const uint32_t m = pmap[c >> (kBucketShift - kCellShift)];
+        const uint64_t pc = (uint64_t)(m >> 1) << kBucketShift;
+        const uint64_t plane = (m & 1u) ? pc + ((c & ((1u << (kBucketShift - kCellShift)) - 1u)) << kCellShift) : pc;
+        word = (uint32_t)(plane >> kCellShift) | ((m & 1u) << 31);
+    } else {
+        word = (uint32_t)c | (1u << 31);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const long long lo = (long long)(c << kCellShift) + (t == 0 ? shift_s : shift_e);
+        uint32_t a = 0, b = n_points;                      // first point >= lo
+        while (a < b) {
+            const uint32_t mid = a + ((b - a) >> 1);
+            if ((long long)points[mid] < lo) a = mid + 1u; else b = mid;
+        }
+        uint32_t bits = 0;
+        for (uint32_t j = a; j < n_points && (long long)points[j] < lo + 32; j++) bits |= 1u << (uint32_t)((long long)points[j] - lo);
+        (t == 0 ? cell_s : cell_e)[c] = make_uint4(a, bits, word, 0u);
+    }
+}
+
 }   // namespace
+
+void launch_build_cells(const uint64_t* points, uint32_t n_points, const uint32_t* pmap, uint64_t n_cells, int32_t shift_s, int32_t shift_e,
+                        uint4* cell_s, uint4* cell_e, hipStream_t s) {
+    if (!n_cells) return;
+    hipLaunchKernelGGL(build_cells_kernel, dim3((uint32_t)((n_cells + 255u) / 256u)), dim3(256), 0, s, points, n_points, pmap, n_cells, shift_s, shift_e,
+                       cell_s, cell_e);
+}
 
 void launch_known_junction_depth(const CountTables& T, hipStream_t s) {
     if (T.n_known == 0) return;
@@ -811,20 +815,24 @@ void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride,
 
 void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;
-    const uint32_t n_chunks = (B.n_frag + kChunk - 1) / kChunk;
-    uint32_t blocks = ((n_chunks + 7u) / 8u) * 8u;            // a multiple of 8 for the XCD mapping
-    if (blocks > 256u * K_WGS_PER_CU) blocks = 256u * K_WGS_PER_CU;
-    hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, T, B);
+    const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
+    const uint32_t n_slices = (n_chunks + kSlice - 1u) / kSlice;
+    const uint32_t most = 256u * K_WGS_PER_CU;
+    hipLaunchKernelGGL(chunk_origin_kernel, dim3((n_chunks + 255u) / 256u), dim3(256), 0, s, T, B, n_chunks);
+    hipLaunchKernelGGL(count_kernel, dim3(n_slices < most ? n_slices : most), dim3(kThreads), 0, s, T, B);
 #ifdef COUNT_PROF
     {
-        static uint32_t h[1024][8];
+        static uint32_t h[2048][2][8];
+        const uint32_t blocks = n_slices < most ? n_slices : most;
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cprof), sizeof h);
-        double a[8] = {0};
-        for (uint32_t w = 0; w < blocks && w < 1024u; w++) for (int k = 0; k < 8; k++) a[k] += h[w][k];
-        fprintf(stderr, "count_prof ticks/wg: fragment phase %.0f | block loop: columns+owner+bucket requests %.0f, junction keys + SpansPoint requests + key search %.0f, "
-                        "junction counters %.0f, events+points+novel %.0f | barrier %.0f | flush junction/point caches %.0f, flush lines+window %.0f\n",
-                a[0] / blocks, a[1] / blocks, a[2] / blocks, a[3] / blocks, a[7] / blocks, a[4] / blocks, a[5] / blocks, a[6] / blocks);
+        for (int w = 0; w < 2; w++) {
+            double a[8] = {0};
+            for (uint32_t b = 0; b < blocks && b < 2048u; b++) for (int k = 0; k < 8; k++) a[k] += h[b][w][k];
+            const double n = blocks < 2048u ? blocks : 2048u;
+            fprintf(stderr, "count_prof wave %d, 10 ns ticks per workgroup: wait at barrier 1 %.0f | flushes %.0f | fragment phase %.0f | wait at barrier 2 %.0f | block phase %.0f | loop overhead %.0f\n",
+                    w ? 3 : 0, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n);
+        }
     }
 #endif
 }

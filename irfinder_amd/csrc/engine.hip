@@ -142,13 +142,18 @@ struct irf_ctx {
     DevBuf<uint32_t> d_chr_len;
     DevBuf<uint8_t> d_chr_owned;
     DevBuf<uint32_t> d_chr_cnt;
-    DevBuf<uint32_t> d_roi_idx, d_roi_bucket, d_roi_cnt;
+    DevBuf<uint32_t> d_roi_idx, d_roi_cnt;
+    DevBuf<uint4> d_roi_bkt;                     // kernels.h: CountTables::roi_bkt
+    DevBuf<uint4> d_chr_rec;                     // kernels.h: CountTables::chr_rec
     DevBuf<uint64_t> d_roi_gstart, d_roi_gend;
     uint32_t n_roi_dev = 0;
     size_t n_sp_dev = 0;                         // SpansPoint entries on owned chromosomes (device tables)
     DevBuf<uint32_t> d_sp_row, d_sp_cnt;
-    DevBuf<uint4> d_bkt;                         // kernels.h: CountTables::bkt
-    DevBuf<uint32_t> d_sp_pos32;                 // SpansPoint: low 32 bits of the points' full coordinates, sorted
+    DevBuf<uint4> d_cell_s, d_cell_e;            // kernels.h: cell tables (plane coordinate + SpansPoint rank per 32-position cell)
+    DevBuf<uint64_t> d_sp_gpos;                  // SpansPoint: the points' full coordinates, sorted (input of the cell tables)
+    DevBuf<uint4> d_jhash;                       // kernels.h: CountTables::jhash
+    DevBuf<unsigned long long> d_chunk_origin;   // kernels.h: CountTables::chunk_origin (sized to the largest batch so far)
+    uint32_t jh_mask = 0;
     DevBuf<uint64_t> d_junc_a, d_junc_b;          // novel-junction records: packed keys (+ sort buffer)
     DevBuf<uint32_t> d_juncw_a, d_juncw_b;        // ... their weights; d_juncw_a.cap follows d_junc_a.cap
     DevBuf<uint32_t> d_wex;                       // exclusive scan of the sorted weights
@@ -403,6 +408,11 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     TRY(upload(this, d_chr_len, chr_len));
     TRY(upload(this, d_chr_owned, chr_owned));
     {
+        std::vector<uint4> rec(std::max<uint32_t>(n, 1u), make_uint4(0u, 0u, 0u, 0u));
+        for (uint32_t i = 0; i < n; i++) rec[i] = make_uint4((uint32_t)chr_base[i], (uint32_t)(chr_base[i] >> 32), chr_len[i], chr_owned[i] ? 1u : 0u);
+        TRY(upload(this, d_chr_rec, rec));
+    }
+    {
         if (clear_stream) HIP_TRY(hipStreamSynchronize(clear_stream));
         for (auto& sp : spare) sp.release();      // (a new map: the spare planes are allocated again when first needed)
         hipError_t e = d_diff.reserve(2 * plane_stride);
@@ -437,21 +447,23 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             gs.push_back(base + ref.roi_start[i]); ge.push_back(base + ref.roi_end[i]); fi.push_back(i);
         }
         n_roi_dev = (uint32_t)fi.size();
+        // per bucket: the first ROI that ends at or after the bucket's start, with its extent inline (kernels.h: roi_bkt)
         const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
-        std::vector<uint32_t> bucket(nb);
+        std::vector<uint4> bucket(nb);
         size_t p = 0;
         for (uint64_t b = 0; b < nb; b++) {
             while (p < ge.size() && ge[p] < (b << dev::kBucketShift)) p++;
-            bucket[b] = (uint32_t)p;
+            if (p < ge.size()) bucket[b] = make_uint4((uint32_t)p, (uint32_t)gs[p], (uint32_t)ge[p], (uint32_t)((gs[p] >> 32) & 0xffffu) | (uint32_t)((ge[p] >> 32) << 16));
+            else bucket[b] = make_uint4((uint32_t)p, 0u, 0u, 0u);
         }
         TRY(upload(this, d_roi_gstart, gs));
         TRY(upload(this, d_roi_gend, ge));
         TRY(upload(this, d_roi_idx, fi));
-        TRY(upload(this, d_roi_bucket, bucket));
+        TRY(upload(this, d_roi_bkt, bucket));
     }
     // ---- SpansPoint: (slot,pos)-sorted; reference-only chromosomes at the tail ----
     n_sp = (uint32_t)ref.sp_pos.size();
-    std::vector<uint32_t> sp_bucket_h;
+    if (P.sp_overhang_left > (1u << 20) || P.sp_overhang_right > (1u << 20)) return fail(IRF_E_ARG, "SpansPoint overhang beyond 2^20");
     n_sp_dev = 0;
     {
         std::vector<uint64_t> key(n_sp);
@@ -467,24 +479,24 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             const uint32_t sl = sp_slot[i];
             if (sl < n && chr_owned[sl] && sp_pos_sorted[i] <= chr_len[sl]) { gpos.push_back(chr_base[sl] + sp_pos_sorted[i]); row.push_back(i); }
         }
-        // bucket[b] = first owned point with gpos >= b << kBucketShift
-        const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
-        std::vector<uint32_t> bucket(nb);
-        {
-            size_t p = 0;
-            for (uint64_t b = 0; b < nb; b++) {
-                while (p < gpos.size() && gpos[p] < (b << dev::kBucketShift)) p++;
-                bucket[b] = (uint32_t)p;
-            }
-        }
         n_sp_dev = gpos.size();
-        {   // the count kernel compares points with block ends modulo 2^32 (all within one block span of each other)
-            std::vector<uint32_t> lo32(gpos.size() + 4, 0u);     // + four spare entries: the kernel loads four at a time from any index
-            for (size_t i = 0; i < gpos.size(); i++) lo32[i] = (uint32_t)gpos[i];
-            TRY(upload(this, d_sp_pos32, lo32));
-        }
+        if (n_sp_dev >= 0xffffffffull) return fail(IRF_E_RANGE, "too many SpansPoint positions");
         TRY(upload(this, d_sp_row, row));
-        sp_bucket_h.swap(bucket);
+        // the cell tables: plane word + point rank / bits per 32-position cell, built on the device
+        {
+            std::vector<uint64_t> gp(gpos);
+            if (gp.empty()) gp.push_back(0);
+            TRY(upload(this, d_sp_gpos, gp));
+            const uint64_t n_cells = (full_size >> dev::kCellShift) + 2;
+            hipError_t e = d_cell_s.reserve(n_cells);
+            if (e == hipSuccess) e = d_cell_e.reserve(n_cells);
+            if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the cell tables failed");
+            const int32_t lo_add = (int32_t)(P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u));
+            const int32_t hi_sub = (int32_t)(P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u));
+            dev::launch_build_cells(d_sp_gpos.p, (uint32_t)n_sp_dev, pmap.empty() ? nullptr : d_pmap.p, n_cells, lo_add, 1 - hi_sub, d_cell_s.p,
+                                    d_cell_e.p, stream);
+            HIP_TRY(hipGetLastError());
+        }
     }
     // ---- known junctions sorted by (slot,left,right) ----
     {
@@ -513,27 +525,21 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         n_known_dev = (uint32_t)kkeys.size();
         n_kj = (uint32_t)kj_left.size();
         {
-            const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
-            std::vector<uint32_t> bucket(nb);
-            size_t p = 0;
-            for (uint64_t b = 0; b < nb; b++) {
-                while (p < kkeys.size() && (kkeys[p] >> dev::kJuncSpanBits) < (b << dev::kBucketShift)) p++;
-                bucket[b] = (uint32_t)p;
+            // the count kernel's junction table: open addressing on junction_hash, load <= 1/32 (kernels.h: jhash)
+            uint64_t slots = 1024;
+            while (slots < 32ull * kkeys.size()) slots <<= 1;
+            while (slots > (1ull << 27) && slots > 4ull * kkeys.size()) slots >>= 1;
+            if (slots > (1ull << 31)) return fail(IRF_E_RANGE, "too many known junctions");
+            jh_mask = (uint32_t)(slots - 1);
+            std::vector<uint4> tab(slots, make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u));
+            for (size_t k = 0; k < kkeys.size(); k++) {
+                if (k && kkeys[k] == kkeys[k - 1]) continue;          // a junction listed twice in ref-sj.ref: its first row counts
+                const uint32_t lo = (uint32_t)kkeys[k], hi = (uint32_t)(kkeys[k] >> 32);
+                uint32_t sl = dev::junction_hash(lo, hi) & jh_mask;
+                while ((tab[sl].x & tab[sl].y) != 0xffffffffu) sl = (sl + 1u) & jh_mask;
+                tab[sl] = make_uint4(lo, hi, krow[k], 0u);
             }
-            // the count kernel's bucket table: plane map + SpansPoint range + known-junction range per bucket
-            std::vector<uint4> bk(nb);
-            auto cnt16 = [](const std::vector<uint32_t>& v, uint64_t b, size_t total) -> uint32_t {
-                const uint64_t n = (b + 1 < v.size() ? v[b + 1] : (uint32_t)total) - (uint64_t)v[b];
-                return n < 0xffffull ? (uint32_t)n : 0xffffu;
-            };
-            for (uint64_t b = 0; b < nb; b++) {
-                bk[b].x = pmap.empty() ? 0u : pmap[b];
-                bk[b].y = sp_bucket_h[b];
-                bk[b].z = bucket[b];
-                bk[b].w = cnt16(sp_bucket_h, b, n_sp_dev) | (cnt16(bucket, b, kkeys.size()) << 16);
-            }
-            TRY(upload(this, d_bkt, bk));
-            std::vector<uint32_t>().swap(sp_bucket_h);
+            TRY(upload(this, d_jhash, tab));
         }
         known_keys_h = kkeys;
         TRY(upload(this, d_known_keys, kkeys));
@@ -743,19 +749,17 @@ dev::CountTables irf_ctx::count_tables() {
     T.n_chr = n_chr; T.n_roi = n_roi; T.n_sp = n_sp;
     T.junc_min_flank = P.junc_min_flank;
     T.sp_min_len = P.sp_overhang_left + P.sp_overhang_right;
-    T.sp_lo_add = P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u);
-    T.sp_hi_sub = P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u);
-    T.ablate = (uint32_t)env_u64("IRF_ABLATE", 0);          // 0 unless built with -DIRF_DIAG
-    T.plane_stride = plane_stride; T.full_size = full_size; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
+    T.plane_stride = plane_stride; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
     T.junc_capacity = d_junc_a.cap;
-    T.chr_base = d_chr_base.p; T.chr_len = d_chr_len.p; T.chr_owned = d_chr_owned.p;
+    T.chr_rec = d_chr_rec.p; T.cell_s = d_cell_s.p; T.cell_e = d_cell_e.p; T.jhash = d_jhash.p; T.jh_mask = jh_mask;
     T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.dirty = d_dirty.p; T.chr_cnt = d_chr_cnt.p;
-    T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p; T.roi_bucket = d_roi_bucket.p;
+    T.roi_bkt = d_roi_bkt.p; T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
-    T.sp_pos32 = d_sp_pos32.p; T.n_sp_dev = (uint32_t)n_sp_dev; T.sp_row = d_sp_row.p; T.bkt = d_bkt.p; T.sp_cnt = d_sp_cnt.p;
+    T.sp_row = d_sp_row.p; T.sp_cnt = d_sp_cnt.p;
     T.known_keys = d_known_keys.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
     T.known_dir = d_known_dir.p; T.dir_votes = d_scalars.p + 3;
     T.junc_keys = d_junc_a.p; T.junc_w = d_juncw_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
+    T.chunk_origin = d_chunk_origin.p;
     return T;
 }
 
@@ -855,7 +859,15 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
         B.frag_chr = st->frag_chr.p; B.frag_flags = st->frag_flags.p; B.frag_start = st->frag_start.p; B.frag_end = st->frag_end.p;
         B.frag_blk_off = st->frag_blk_off.p; B.blk_start = st->blk_start.p; B.blk_len = st->blk_len.p; B.blk_read = st->blk_read.p;
     }
-    if (input_order == IRF_ORDER_ANY && B.n_frag > 1024u) TRY(reorder(B));       // (a batch of one chunk has nothing to gain)
+    if (input_order == IRF_ORDER_ANY && B.n_frag > 1024u) TRY(reorder(B));       // (a batch of a few chunks has nothing to gain)
+    {
+        // (grown on the stream's own time line: a kernel of an earlier batch may still read the old array)
+        const size_t need = (size_t)B.n_frag / 256 + 1;
+        if (need > d_chunk_origin.cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (d_chunk_origin.reserve(need + need / 4) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the chunk table failed");
+        }
+    }
     if (count_events_used == count_events.size()) {
         hipEvent_t a, z;
         HIP_TRY(hipEventCreate(&a));

@@ -39,63 +39,78 @@ enum ErrBits : uint32_t {
     ERR_CSR = 32u              // frag_blk_off of a device-resident batch: not non-decreasing, beyond n_blk, or not spanning [0, n_blk]
 };
 
+// ---- tables of the count kernel ------------------------------------------------
+// Everything the count kernel asks about a POSITION comes from one 16-byte record of the 32-position cell the position
+// lies in: the plane coordinate (for the difference events) and the rank of the position among the SpansPoint points (a
+// block counts the points in [bs + sp_lo_add, be - sp_hi_sub]: the difference of two ranks, and the ranks are the indices
+// of the points).  Two tables, one asked with block starts, one with block ends; their point bits are pre-shifted by the
+// overhang, so that the cell of bs answers for bs + sp_lo_add and the cell of be for be - sp_hi_sub + 1:
+//   x = points in front of the cell's first (shifted) position, y = bit i: a point at shifted position i of the cell,
+//   z = (plane coordinate of the cell's first position >> 5) | kept << 31 — a cell of a bucket that is not kept maps, whole,
+//       to the start of the next kept bucket (plane_coord above) —, w = 0.
+constexpr int kCellShift = 5;
+__host__ __device__ inline uint32_t junction_hash(uint32_t key_lo, uint32_t key_hi) {
+    uint32_t x = key_lo * 0x9E3779B1u + key_hi * 0x85EBCA77u;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+    return x;
+}
+
 struct CountTables {
     uint32_t n_chr;
     uint32_t n_roi;
     uint32_t n_sp;
     uint32_t junc_min_flank;
     uint32_t sp_min_len;       // block is considered only if len > sp_min_len (= L + R)
-    uint32_t sp_lo_add;        // candidates are the points in [bs + sp_lo_add, be - sp_hi_sub]
-    uint32_t sp_hi_sub;
-    uint32_t ablate;           // diagnostic only (IRF_ABLATE env): bit0 depth, 1 SpansPoint, 2 ROI, 3 junction, 4 chr, 6 no folding of known-junction events
-    uint64_t plane_stride;     // elements per strand plane of the difference array (compact coordinates)
-    uint64_t full_size;        // size of the full coordinate space (chr_base + pos); junction keys, point / junction buckets
-    const uint32_t* pmap;      // full -> plane coordinates, one entry per 512-position bucket; nullptr = identity
-    // everything the count kernel needs to know about a 512-position bucket of the full coordinate space, in one
-    // 16-byte load: x = pmap entry, y = first SpansPoint at or after the bucket start, z = first known-junction key
-    // whose left end is at or after the bucket start, w = (points in the bucket) | (known keys in the bucket) << 16,
-    // each saturating at 0xffff (then the next entry's y / z closes the range).  [(full_size >> kBucketShift) + 2]
-    const uint4* bkt;
-    uint64_t junc_capacity;
-    const uint64_t* chr_base;  // [n_chr]  offset of the chromosome inside a plane
-    const uint32_t* chr_len;   // [n_chr]
-    const uint8_t* chr_owned;  // [n_chr]
-    int32_t* diff;             // [2][plane_stride]  +1 at block start, -1 at block end
-    uint32_t* seg_sum;         // [2][plane_stride >> kSegShift]  sum of every 256-position segment of diff
-    uint32_t* chr_cnt;         // [n_chr][2]
-    // ROIs of owned chromosomes sorted by end, in full coordinates, + bucket index on the end
-    const uint64_t* roi_gstart;
-    const uint64_t* roi_gend;
-    const uint32_t* roi_idx;    // file index of the sorted ROI
-    const uint32_t* roi_bucket; // [(full_size >> kBucketShift) + 2] first ROI with gend >= b << kBucketShift
     uint32_t n_roi_dev;
-    uint32_t n_sp_dev;         // entries of sp_pos32 / sp_row
-    uint32_t* roi_cnt;         // [2][n_roi]
-    // SpansPoint: points on owned chromosomes in full coordinates (range per bucket: bkt)
-    const uint32_t* sp_pos32;  // [n_sp_dev] the points' full coordinates, sorted, low 32 bits (compared modulo 2^32 with
-                               // block ends at most one block span + two buckets away)
-    const uint32_t* sp_row;    // [n_sp_own] row in sp_cnt
-    uint32_t* sp_cnt;          // [2][n_sp]
-    // known junctions (ref-sj.ref) on owned chromosomes: events that hit one are counted in place,
-    // only novel junctions go through the event buffer + sort
-    const uint64_t* known_keys;   // sorted (global_left << 28 | span)
-    const uint32_t* known_kjidx;  // row of the known-junction table (all of ref-sj, (slot,left,right) order)
-    uint32_t n_known;             // entries of known_keys
-    uint32_t n_kj;                // rows of the known-junction table
+    uint32_t n_kj;             // rows of the known-junction table
+    uint32_t n_known;          // entries of known_keys
+    uint32_t jh_mask;          // slots of jhash - 1
+    uint32_t pad0;
+    uint64_t plane_stride;     // elements per strand plane of the difference array (compact coordinates)
+    uint64_t junc_capacity;
+    const uint4* chr_rec;      // [n_chr] x, y = offset of the chromosome in the full coordinate space, z = length, w = owned
+    const uint4* cell_s;       // [(full_size >> 5) + 2] asked with block starts (see above)
+    const uint4* cell_e;       // ... with block ends
+    // known junctions (ref-sj.ref) on owned chromosomes, open addressing (linear probing, load <= 1/32) on
+    // junction_hash(key): x, y = key (global_left << 28 | span; all ones = empty), z = row of the known-junction table
+    const uint4* jhash;
+    // FragmentsInROI: per 512-position bucket the first ROI (by end) that ends at or after the bucket's start:
+    // x = its index, y / z = low words of its start / end (full coordinates), w = their high halves (start | end << 16)
+    const uint4* roi_bkt;
+    const uint64_t* roi_gstart;   // ROIs of owned chromosomes sorted by end, in full coordinates (the walk behind roi_bkt)
+    const uint64_t* roi_gend;
+    const uint32_t* roi_idx;      // file index of the sorted ROI
+    uint32_t* roi_cnt;            // [2][n_roi]
+    uint32_t* chr_cnt;            // [n_chr][2]
+    const uint32_t* sp_row;       // [points on owned chromosomes] row in sp_cnt
+    uint32_t* sp_cnt;             // [2][n_sp]
     uint32_t* known_cnt;          // [2][n_kj]
-    // known_junction_depth_kernel only: the strand of every known_keys entry (1 '-', 2 '+', 0/3 unknown) and the two vote
-    // sums of JunctionCount::Directional (reads on a junction whose strand agrees / disagrees with their own)
-    const uint8_t* known_dir;
-    unsigned long long* dir_votes;
-    uint64_t* junc_keys;          // novel-junction event buffer: packed keys ...
-    uint32_t* junc_w;             // ... and their weights (a chunk's events on one junction are merged in LDS first)
-    unsigned long long* junc_count;
-    uint32_t* err_flags;
+    int32_t* diff;                // [2][plane_stride]  +1 at block start, -1 at block end
+    uint32_t* seg_sum;            // [2][plane_stride >> kSegShift]  sum of every 256-position segment of diff
     // One byte per 64-byte line of the planes ([plane_stride / 16][2 strands]): set by whatever adds to the line (or may
     // have).  The planes of a sample are mostly untouched lines (introns at low depth), so clearing them for the next
     // sample (launch_sparse_clear) writes the marked lines only instead of all of them.
     uint8_t* dirty;
+    uint64_t* junc_keys;          // novel-junction event buffer: packed keys ...
+    uint32_t* junc_w;             // ... and their weights (a chunk's events on one junction are merged in LDS first)
+    unsigned long long* junc_count;
+    uint32_t* err_flags;
+    // [fragments of the batch / 256, rounded up] where the count kernel puts the window of every chunk of 256 fragments
+    // (written by a kernel of launch_count in front of the count kernel)
+    unsigned long long* chunk_origin;
+    // known_junction_depth_kernel only: the plane map, the sorted keys (global_left << 28 | span), their rows and strands
+    // (1 '-', 2 '+', 0/3 unknown) and the two vote sums of JunctionCount::Directional
+    const uint32_t* pmap;         // full -> plane coordinates, one entry per 512-position bucket; nullptr = identity
+    const uint64_t* known_keys;
+    const uint32_t* known_kjidx;
+    const uint8_t* known_dir;
+    unsigned long long* dir_votes;
 };
+
+// cell tables (device-built at irf_chr_map_update): points = sorted full coordinates of the SpansPoint points on owned
+// chromosomes; shift_s = sp_lo_add, shift_e = 1 - sp_hi_sub (see above)
+void launch_build_cells(const uint64_t* points, uint32_t n_points, const uint32_t* pmap, uint64_t n_cells, int32_t shift_s, int32_t shift_e,
+                        uint4* cell_s, uint4* cell_e, hipStream_t s);
 
 struct BatchDev {
     uint32_t n_frag, n_blk;
