@@ -12,32 +12,39 @@
 //                      difference events need anyway (kernels.h: cell tables)
 //   * JunctionCount  : one probe of a sparse hash table of the known junctions (ref-sj.ref);
 //                      a hit bumps that junction's counter (LDS-cached), novel junctions are
-//                      merged per slice in an LDS table, appended as packed
-//                      (chr,left,span,strand) records and sort-reduced at finalize
+//                      merged in an LDS table, appended as packed (chr,left,span,strand)
+//                      records and sort-reduced at finalize
 // All outputs are commutative integer sums, so any batch order gives identical
 // results.  Integer work bound by memory latency and by the vector-memory instruction rate: no MFMA.
 //
-// Shape of the kernel (round 3: the block phase no longer searches).  The input is CSR (fragments -> blocks).  A
-// workgroup takes SLICES of the (coordinate-sorted) batch, kSlice chunks of 256 consecutive fragments each, and keeps its
-// LDS accumulators across the chunks of a slice:
-//   F. fragment phase, one fragment per lane: the chromosome record, FragmentsInChr, FragmentsInROI; the fragment's
-//      facts (coordinate base, strand, chromosome length) go to LDS and the lane writes its id over the OWNER entries of
-//      its blocks (with a first / last flag), so that
-//   B. the block phase, one block per lane in strides of 63 (lane 63 only looks ahead), needs no search for the owning
-//      fragment: one LDS read gives the owner, one its facts.  Every table question about a position is one 16-byte
-//      cell record: the cell of the block start and the cell of the block end give both plane coordinates and both
-//      SpansPoint ranks; the junction to the right of the block is one probe of the hash table.  Three table loads per
-//      block, all independent of each other.  The successor block's columns, validity and start cell come from the next
-//      lane by DPP.  A block owns the junction to its right and the two difference events next to it (its own end, its
-//      successor's start): a read on a known junction costs one LDS increment of that junction's counter, which also
-//      stands for both events (known_junction_depth_kernel applies them once per junction at finalize).
-//   The difference window is circular (cell = plane position mod kWin) and SCROLLS with the chunks: what a chunk's first
-//   fragment leaves behind is flushed (one global atomic per non-zero cell, whole 64-byte lines), the rest stays and keeps
-//   merging events of later chunks; caches of far lines, junction counters, point counters and novel junctions are flushed
-//   every kFlushEvery chunks.
+// Shape of the kernel (round 3).  The input is CSR (fragments -> blocks).  A workgroup is kWorkers WORKER waves and one
+// FLUSHER wave.  It takes SLICES of the (coordinate-sorted) batch, kSlice chunks of kWorkers x 64 consecutive fragments
+// each, and keeps its LDS accumulators across the chunks of a slice.  Per chunk, between two workgroup barriers each:
+//   F. fragment phase (workers), one fragment per lane: the chromosome record, FragmentsInChr, FragmentsInROI; the
+//      fragment's facts (coordinate base, strand, chromosome length) go to LDS and the lane writes its id over the OWNER
+//      entries of its blocks (with a first / last flag).  MEANWHILE the flusher wave sends what the previous chunks left in
+//      LDS to the tables: the part of the difference window the new chunk has scrolled past, the overflow queue, and every
+//      few chunks the caches (far lines, junction / point / ROI counters, novel junctions).
+//   B. block phase (workers), one block per lane in strides of 63 (lane 63 only looks ahead): one LDS read gives the owner,
+//      one its facts — no search.  Every table question about a position is one 16-byte cell record: the cell of the block
+//      start and the cell of the block end give both plane coordinates and both SpansPoint ranks; the junction to the right
+//      of the block is one probe of the hash table.  Three table loads per block, all independent of each other.  The
+//      successor block's columns, validity and start cell come from the next lane by DPP.  A block owns the junction to its
+//      right and the two difference events next to it (its own end, its successor's start): a read on a known junction
+//      costs one LDS increment of that junction's counter, which also stands for both events (known_junction_depth_kernel
+//      applies them once per junction at finalize).
+// Why a flusher wave: gfx9 retires a wave's vector-memory operations in order under one counter, and a memory-side atomic
+// takes microseconds to be acknowledged, so a wave that has issued ONE global atomic waits that long for its next load.
+// Measured on configs[1]: the 1.1 M ROI atomics alone cost 0.3 of 2.95 ms.  Worker waves therefore issue no global atomic
+// and no global store at all: what does not fit an LDS accumulator goes to an LDS queue (only when that is full, too, does
+// a worker touch the tables itself), and the one wave that issues atomics never waits for a load.
+// The difference window is circular (cell = plane position mod kWin) and SCROLLS with the chunks: what a chunk's first
+// fragment leaves behind is flushed (one global atomic per non-zero cell, whole 64-byte lines), the rest stays and keeps
+// merging events of later chunks.
 #include "kernels.h"
 
 #include <cstdio>
+#include <cstring>
 
 namespace irf {
 namespace dev {
@@ -45,18 +52,35 @@ namespace dev {
 namespace {
 
 #ifdef COUNT_PROF
-// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of waves 0 and 3 per phase and workgroup
-__device__ uint32_t g_cprof[2048][2][8];
-#define CPROF(k) do { if (lane == 0u && (wave == 0u || wave == 3u)) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
+// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of worker wave 0, the last worker
+// wave and the flusher wave per phase and workgroup
+__device__ uint32_t g_cprof[2048][3][8];
+#define CPROF(k) do { if (lane == 0u && prof_on) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
+// ... and what the flusher did, summed over the launch: 0 window steps looked at, 1 of them not empty, 2 line steps not empty,
+// 3 queue entries, 4 chunks whose window jumped, 5 cache flushes, 6 chunks
+__device__ unsigned long long g_cstat[8];
+#define CSTAT(k, n) do { if (lane == 0u) s_cstat_local[k] += (n); } while (0)
 #else
 #define CPROF(k) do { } while (0)
+#define CSTAT(k, n) do { } while (0)
 #endif
 
+#ifndef K_WORKERS
+#define K_WORKERS 6
+#endif
+#ifndef K_FLUSHERS
+#define K_FLUSHERS 2
+#endif
+#if K_WORKERS > 4
+#define K_BIG 1
+#else
+#define K_BIG 0
+#endif
 #ifndef K_WIN
-#define K_WIN 2048
+#define K_WIN (K_BIG ? 4096 : 2048)
 #endif
 #ifndef K_LINES
-#define K_LINES 128
+#define K_LINES (K_BIG ? 256 : 128)
 #endif
 #ifndef K_JCACHE
 #define K_JCACHE 256
@@ -65,36 +89,42 @@ __device__ uint32_t g_cprof[2048][2][8];
 #define K_PCACHE 128
 #endif
 #ifndef K_TILE
-#define K_TILE 1024
+#define K_TILE (K_BIG ? 2048 : 1024)
 #endif
 #ifndef K_SLICE
-#define K_SLICE 16
+#define K_SLICE (K_BIG ? 8 : 16)
 #endif
 #ifndef K_FLUSH
-#define K_FLUSH 4
+#define K_FLUSH (K_BIG ? 2 : 4)
 #endif
 #ifndef K_WGS_PER_CU
-#define K_WGS_PER_CU 5
+#define K_WGS_PER_CU (K_BIG ? 3 : 5)
 #endif
 #ifndef K_BU
-#define K_BU 2
+#define K_BU 1
 #endif
-constexpr int kThreads = 256;
-constexpr uint32_t kWaves = kThreads / 64;
-constexpr uint32_t kChunk = kThreads;               // fragments per chunk: one per lane
+constexpr uint32_t kWorkers = K_WORKERS;            // worker waves per workgroup; the waves behind them are the flushers:
+constexpr uint32_t kFlushers = K_FLUSHERS;          // one (window, queue, caches) or two (window + queue | caches)
+static_assert(kFlushers == 1u || kFlushers == 2u, "K_FLUSHERS");
+constexpr int kThreads = (K_WORKERS + K_FLUSHERS) * 64;
+constexpr int kWavesPerSimd = (K_WGS_PER_CU * (K_WORKERS + K_FLUSHERS) + 3) / 4;
+constexpr uint32_t kChunk = kWorkers * 64u;         // fragments per chunk: one per worker lane
 constexpr uint32_t kTile = K_TILE;                  // owner entries: blocks of a chunk are processed in tiles of this many
 constexpr uint32_t kSlice = K_SLICE;                // chunks per slice (a workgroup's unit of work; accumulators live this long)
 constexpr uint32_t kFlushEvery = K_FLUSH;           // chunks between two flushes of the caches
 constexpr int kBU = K_BU;                           // strides a wave works on at once (their table loads are in flight together)
 constexpr uint32_t kStride = 63;                    // blocks per wave and step (lane 63 is the look-ahead)
-constexpr uint32_t kChrBins = 128;                  // LDS histogram covers refIDs < 64; larger ones go straight to global
+constexpr uint32_t kChrTab = 64;                    // references whose record is kept in LDS
+constexpr uint32_t kChrBins = 128;                  // LDS histogram covers refIDs < 64; larger ones go through the queue
 constexpr uint32_t kJCache = K_JCACHE;              // LDS cache of known-junction counters (direct-mapped on the junction's row)
 constexpr uint32_t kEmpty = 0xffffffffu;
 constexpr uint32_t kLines = K_LINES;                // LDS cache of 16-position lines of the difference planes outside the window
 constexpr uint32_t kWin = K_WIN;                    // positions of the LDS difference-array window (both strands in one int32)
-constexpr uint32_t kPCache = K_PCACHE;              // LDS cache of SpansPoint counters (direct-mapped on the point index)
+constexpr uint32_t kPCache = K_PCACHE;              // LDS cache of SpansPoint counters (direct-mapped on the point's row)
+constexpr uint32_t kRCache = 64;                    // LDS cache of ROI counters (direct-mapped on the ROI's row)
 constexpr uint32_t kNovelQ = 64;                    // LDS queue of novel-junction events (those the table below has no room for)
 constexpr uint32_t kNovelH = 128;                   // LDS table that merges novel-junction events by key (open addressing, 4 probes)
+constexpr uint32_t kOQ = 256;                       // LDS queue of updates that found their cache slot taken (drained every chunk)
 constexpr unsigned long long kEmpty64 = ~0ull;      // (no event has bit 63 set)
 // The window and the line cache keep both strands of a position as 16-bit halves of one word.  A chunk with more blocks than
 // kWinMaxBlocks bypasses them; everything is flushed before the events added since the last complete flush can exceed 2^15.
@@ -102,10 +132,23 @@ constexpr uint32_t kWinMaxBlocks = 4000;
 constexpr uint32_t kEvFlush = 22000;                // + 2 * kWinMaxBlocks < 32768
 constexpr unsigned long long kNoWin = ~0ull;
 constexpr uint32_t kFragValid = 1u << 31, kFragDir = 1u << 30, kFragBaseMask = (1u << 28) - 1u;   // base >> 6 (base is a multiple of 64, < 2^34)
-constexpr uint32_t kOwnFirst = 0x4000u, kOwnLast = 0x8000u;
+constexpr uint32_t kOwnFirst = 0x4000u, kOwnLast = 0x8000u, kOwnMask = 0x1ffu;
+static_assert(kChunk <= 512u, "owner ids are 9 bits");
 static_assert(kWin % 64u == 0u && (kWin & (kWin - 1u)) == 0u, "K_WIN");
-static_assert((kLines * 16u) % kThreads == 0u, "the line flush runs with whole waves (DPP sums)");
-static_assert(kEvFlush + 2u * kWinMaxBlocks < 32768u, "packed 16-bit halves");
+static_assert((kLines * 16u) % 64u == 0u, "the line flush runs with whole waves (DPP sums)");
+static_assert(kEvFlush + 2u * kWinMaxBlocks < 32768u && 2u * kFlushEvery * kWinMaxBlocks <= 32768u, "packed 16-bit halves");
+
+// entries of the overflow queue: kind << 62 | strand << 61 | ...
+constexpr unsigned long long kOqPlane = 0ull << 62;     // | minus << 60 | plane position: one difference event
+constexpr unsigned long long kOqKnown = 1ull << 62;     // | count << 32 | row of known_cnt
+constexpr unsigned long long kOqPoint = 2ull << 62;     // | count << 32 | row of sp_cnt
+constexpr unsigned long long kOqRoi = 3ull << 62;       // | count << 32 | row of roi_cnt;  with bit 60: index into chr_cnt
+
+#define AS1 __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Pointers read out of the table block are generic to the compiler (flat instructions: both wait counters); cast to the
+// global address space where they are used.
+template <class X> __device__ __forceinline__ AS1 X* gp(X* p) { return (AS1 X*)p; }
 
 struct Lds {
     uint2 facts[kChunk];               // x = base >> 6 | strand << 30 | counted << 31, y = chromosome length
@@ -115,14 +158,21 @@ struct Lds {
     int32_t lcnt[kLines + 1][16];      // both strands of a position in one word, as in the window; line kLines: idle
     uint32_t jtag[kJCache];            // known-junction cache: row of the known-junction table
     uint32_t jcnt[2][kJCache];
-    uint32_t ptag[kPCache];            // SpansPoint cache: index of the point among the points on owned chromosomes
+    uint32_t ptag[kPCache];            // SpansPoint cache: row of sp_cnt
     uint32_t pcnt[2][kPCache];
+    uint32_t rtag[kRCache];            // ROI cache: row of roi_cnt
+    uint32_t rcnt[2][kRCache];
     unsigned long long nq[kNovelQ];
     unsigned long long nh_key[kNovelH];
     uint32_t nh_cnt[kNovelH];
+    unsigned long long oq[kOQ];
     uint32_t chr[kChrBins];
+    u32x4 chrtab[kChrTab];             // chr_rec of the first kChrTab references (the fragment phase then waits for no load)
+    // the claimed slots of the four caches, in the order they were claimed (the flusher walks these, not the caches)
+    uint16_t llist[kLines], jlist[kJCache], plist[kPCache], rlist[kRCache];
+    uint32_t ll_n, jl_n, pl_n, rl_n;
     uint32_t wmax[2];                  // highest window offset + 1 a chunk touched
-    uint32_t nq_n, nh_n;
+    uint32_t nq_n, nh_n, oq_n;
 };
 
 // Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
@@ -166,33 +216,76 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) {
 #endif
 }
 
+// ---- the tables (global atomics: the flusher wave, and a worker whose queue is full) ----------------------------
 // The sum of every 256-position segment of the planes is kept next to them (seg_sum; its exclusive scan is the depth
 // carry of stats.hip), so that finalize does not have to read the planes once more just to add them up.
 __device__ __forceinline__ void seg_add(const CountTables& T, uint32_t dir, uint64_t c, int v) {
-    __hip_atomic_fetch_add(T.seg_sum + (uint64_t)dir * (T.plane_stride >> kSegShift) + (c >> kSegShift), (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef K_DIAG_NO_ATOMICS
+    return;
+#endif
+    __hip_atomic_fetch_add(gp(T.seg_sum) + (uint64_t)dir * (T.plane_stride >> kSegShift) + (c >> kSegShift), (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (CountTables.dirty: the line of plane position c of strand dir now holds something)
+__device__ __forceinline__ void mark_dirty(const CountTables& T, uint32_t dir, uint64_t c) {
+#ifdef K_DIAG_NO_ATOMICS
+    return;
+#endif
+    gp(T.dirty)[((c >> 4) << 1) + dir] = 1; }
+__device__ __forceinline__ void add_u32(uint32_t* p, uint32_t v) {
+#ifdef K_DIAG_NO_ATOMICS
+    return;
+#endif
+    __hip_atomic_fetch_add(gp(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void oq_apply(const CountTables& T, unsigned long long e) {
+    const uint32_t kind = (uint32_t)(e >> 62), dir = (uint32_t)(e >> 61) & 1u;
+    const uint32_t idx = (uint32_t)e, n = (uint32_t)(e >> 32) & 0x0fffffffu;
+    if (kind == 0u) {
+        const uint64_t c = e & ((1ull << 36) - 1ull);
+        const int v = (e >> 60) & 1ull ? -1 : 1;
+#ifndef K_DIAG_NO_ATOMICS
+        __hip_atomic_fetch_add(gp(T.diff) + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        seg_add(T, dir, c, v);
+        mark_dirty(T, dir, c);
+    } else if (kind == 1u) {
+        add_u32(T.known_cnt + (uint64_t)dir * T.n_kj + idx, n);
+    } else if (kind == 2u) {
+        add_u32(T.sp_cnt + (uint64_t)dir * T.n_sp + idx, n);
+    } else if ((e >> 60) & 1ull) {
+        add_u32(T.chr_cnt + idx, n);
+    } else {
+        add_u32(T.roi_cnt + (uint64_t)dir * T.n_roi + idx, n);
+    }
 }
 
-// (CountTables.dirty: the line of plane position c of strand dir now holds something)
-__device__ __forceinline__ void mark_dirty(const CountTables& T, uint32_t dir, uint64_t c) { T.dirty[((c >> 4) << 1) + dir] = 1; }
+// ---- worker side: LDS accumulators, and the queue when a slot is taken --------------------------------------------
+__device__ __forceinline__ void oq_push(const CountTables& T, Lds& S, unsigned long long e) {
+    const uint32_t q = atomicAdd(&S.oq_n, 1u);
+    if (q < kOQ) S.oq[q] = e;
+    else oq_apply(T, e);            // (queue full: the worker pays for the atomic itself)
+}
 
 // A difference event outside the window, at plane position (p5 << 5) + sub: the line cache, else (line slot taken by
-// another line, or the chunk bypasses the packed accumulators) a global atomic.
+// another line, or the chunk bypasses the packed accumulators) the queue.
 __device__ __forceinline__ void far_event(const CountTables& T, Lds& S, bool use_win, uint32_t p5, uint32_t sub, uint32_t dir, int v) {
     // (a line holds both strands, packed like the window: unstranded reads put both on the same positions; one
     //  compare-and-swap claims an empty slot or returns the line that holds it; the counter update is predicated like the
     //  window's — line kLines is nobody's — so only a conflict is a branch)
     const uint32_t want = (p5 << 1) | (sub >> 4);
-    const uint32_t slot = want & (kLines - 1u);
+    uint32_t slot = want & (kLines - 1u);
     uint32_t old = want + 1u;
-    if (use_win) old = atomicCAS(&S.ltag[slot], kEmpty, want);
+    if (use_win) {
+        old = atomicCAS(&S.ltag[slot], kEmpty, want);
+        if (old != kEmpty && old != want) {         // taken by another line: the line's second slot
+            slot = (slot ^ (kLines >> 1) ^ ((want >> 8) & (kLines / 2u - 1u))) & (kLines - 1u);
+            old = atomicCAS(&S.ltag[slot], kEmpty, want);
+        }
+        if (old == kEmpty) S.llist[atomicAdd(&S.ll_n, 1u)] = (uint16_t)slot;      // (claimed: at most kLines claims between two flushes)
+    }
     const bool mine = use_win && (old == kEmpty || old == want);
     atomicAdd(&S.lcnt[mine ? slot : kLines][sub & 15u], mine ? (dir ? v * 65536 : v) : 0);
-    if (!mine) {
-        const uint64_t c = ((uint64_t)p5 << 5) + sub;
-        __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seg_add(T, dir, c, v);
-        mark_dirty(T, dir, c);
-    }
+    if (!mine) oq_push(T, S, kOqPlane | (unsigned long long)dir << 61 | (v < 0 ? 1ull << 60 : 0ull) | (((unsigned long long)p5 << 5) + sub));
 }
 
 // One difference event with a predicate instead of a branch around the call.  w = the plane word of the position's cell
@@ -212,26 +305,19 @@ __device__ __forceinline__ void depth_event(const CountTables& T, Lds& S, uint32
     if (pred && !near) far_event(T, S, use_win, p5, subk, dir, v);
 }
 
-// One read of strand dir on the known junction of row `row`: the LDS counter, or (slot taken by another junction) straight
-// to the table.  The counter also stands for the read's two difference events next to the junction: they are applied once
-// per junction and sample by known_junction_depth_kernel at finalize.
-__device__ __forceinline__ void junction_add(const CountTables& T, Lds& S, uint32_t row, uint32_t dir) {
-    const uint32_t slot = row & (kJCache - 1u);
-    uint32_t tag = S.jtag[slot];
+// One count of strand dir for row `row` in a direct-mapped LDS cache (tags, two counter rows); slot taken: the queue.
+template <uint32_t N>
+__device__ __forceinline__ void cache_add(const CountTables& T, Lds& S, uint32_t* tags, uint32_t (*cnt)[N], uint16_t* list, uint32_t* list_n, uint32_t row,
+                                          uint32_t dir, unsigned long long oq_kind) {
+    const uint32_t slot = row & (N - 1u);
+    uint32_t tag = tags[slot];
     if (tag == kEmpty) {
-        const uint32_t old = atomicCAS(&S.jtag[slot], kEmpty, row);
+        const uint32_t old = atomicCAS(&tags[slot], kEmpty, row);
         tag = old == kEmpty ? row : old;
+        if (old == kEmpty) list[atomicAdd(list_n, 1u)] = (uint16_t)slot;
     }
-    if (tag == row) atomicAdd(&S.jcnt[dir][slot], 1u);
-    else atomicAdd(&T.known_cnt[(uint64_t)dir * T.n_kj + row], 1u);
-}
-
-__device__ __forceinline__ void point_add(const CountTables& T, Lds& S, uint32_t pi, uint32_t dir) {
-    const uint32_t slot = pi & (kPCache - 1u);
-    uint32_t tag = S.ptag[slot];
-    if (tag == kEmpty) { const uint32_t old = atomicCAS(&S.ptag[slot], kEmpty, pi); tag = old == kEmpty ? pi : old; }
-    if (tag == pi) atomicAdd(&S.pcnt[dir][slot], 1u);
-    else atomicAdd(&T.sp_cnt[(uint64_t)dir * T.n_sp + T.sp_row[pi]], 1u);
+    if (tag == row) atomicAdd(&cnt[dir][slot], 1u);
+    else oq_push(T, S, oq_kind | (unsigned long long)dir << 61 | 1ull << 32 | row);
 }
 
 // A read on a novel junction: a packed event for the sort-reduce at finalize.  A slice sits on one locus, so its novel events
@@ -260,106 +346,141 @@ __device__ __forceinline__ void novel_add(const CountTables& T, Lds& S, unsigned
             const uint64_t m = __ballot(1);
             const int lead = __ffsll((long long)m) - 1;
             unsigned long long b = 0;
-            if ((int)lane == lead) b = atomicAdd(T.junc_count, (unsigned long long)__popcll(m));
+            if ((int)lane == lead) b = __hip_atomic_fetch_add(gp(T.junc_count), (unsigned long long)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             b = __shfl(b, lead);
             const unsigned long long slot = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < T.junc_capacity) { T.junc_keys[slot] = ev; T.junc_w[slot] = 1u; } else err |= ERR_JUNC_CAPACITY;
+            if (slot < T.junc_capacity) { gp(T.junc_keys)[slot] = ev; gp(T.junc_w)[slot] = 1u; } else err |= ERR_JUNC_CAPACITY;
         }
     }
 }
 
+// ---- flusher side (one wave) ----------------------------------------------------------------------------------
 // Window cells of the positions win + [0, to): one global atomic per non-zero cell and strand, consecutive lanes =
 // consecutive positions (whole 64-byte lines for the memory-side atomic unit); the cells are left zero.
-__device__ __forceinline__ void flush_window(const CountTables& T, Lds& S, unsigned long long win, uint32_t to, uint32_t lane, uint32_t wave) {
-    for (uint32_t g = wave * 64u; g < to; g += kWaves * 64u) {
-        const uint64_t p = win + g + lane;                              // (win and g are multiples of 64: one segment per wave)
-        const uint32_t idx = (uint32_t)p & (kWin - 1u);
-        const int32_t v = S.tile[idx];
-#ifndef K_NO_SKIP
-        if (__ballot(v != 0) == 0ull) continue;                         // (nothing in these 64 positions)
+__device__ __forceinline__ void flush_window(const CountTables& T, Lds& S, unsigned long long win, uint32_t to, uint32_t lane, uint32_t* s_cstat_local) {
+    // (segment sums and line marks leave once per 256-position segment: the steps of a segment add up first)
+    int32_t acc = 0;                    // packed sums of the current segment (lane 63)
+    uint32_t marks = 0;                 // bit k: step k of the current segment held something
+    auto close_segment = [&](uint64_t seg_pos) {          // seg_pos: the segment's first position
+        const int32_t tot = __builtin_amdgcn_readlane(acc, 63);
+        const int32_t t0 = (int32_t)(int16_t)(uint16_t)(tot & 0xffff), t1 = (tot - t0) >> 16;
+        if (lane >= 62u) {              // lane 63 adds strand 0's sum, lane 62 strand 1's: one instruction
+            const uint32_t dir = 63u - lane;
+            const int32_t v = dir ? t1 : t0;
+            if (v) seg_add(T, dir, seg_pos, v);
+        }
+        // the marks of the segment's 16 lines, both strands: 8 bytes per step that held something
+        if (lane < 4u && ((marks >> lane) & 1u))
+#ifndef K_DIAG_NO_ATOMICS
+            *reinterpret_cast<AS1 unsigned long long*>(gp(T.dirty) + ((((seg_pos >> 8) << 2) + lane) << 3)) = 0x0101010101010101ull;
+#else
+            (void)0;
 #endif
+        acc = 0; marks = 0;
+    };
+    uint64_t cur_seg = ~0ull;
+    for (uint32_t g4 = 0; g4 < to; g4 += 256u) {
+    int32_t v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v4[k] = S.tile[(uint32_t)(win + g4 + 64u * k + lane) & (kWin - 1u)];     // (cells behind `to` are the window's own, too)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t g = g4 + 64u * k;
+        if (g >= to) continue;
+        CSTAT(0, 1u);
+        const uint64_t p = win + g + lane;                              // (win and g are multiples of 64: one segment per step)
+        const uint32_t idx = (uint32_t)p & (kWin - 1u);
+        const int32_t v = v4[k];
+        if (__ballot(v != 0) == 0ull) continue;                         // (nothing in these 64 positions)
+        CSTAT(1, 1u);
+        const uint64_t seg = (win + g) >> 8;
+        if (seg != cur_seg) { if (cur_seg != ~0ull) close_segment(cur_seg << 8); cur_seg = seg; }
         const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
         const int32_t v1 = (v - v0) >> 16;
         if (v) {
-#ifndef K_DIAG_NO_FLUSH_ATOMICS
-            int32_t* d = T.diff + p;
+            AS1 int32_t* d = gp(T.diff) + p;
+#ifndef K_DIAG_NO_ATOMICS
             if (v0) __hip_atomic_fetch_add(d, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v1) __hip_atomic_fetch_add(d + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
             S.tile[idx] = 0;
         }
         // (the two strands' sums in one pass: the packed halves of a sum cannot overflow, see kEvFlush)
-        const int32_t sp = wave_sum_dpp(v);
-        const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
-        if (lane == 63u) {
-#ifndef K_DIAG_NO_FLUSH_ATOMICS
-            if (s0) seg_add(T, 0u, p, s0);
-            if (s1) seg_add(T, 1u, p, s1);
-#endif
-            // the wave's four lines, both strands: eight consecutive marks
-            *reinterpret_cast<unsigned long long*>(T.dirty + ((p >> 6) << 3)) = 0x0101010101010101ull;
-        }
+        acc += wave_sum_dpp(v);
+        marks |= 1u << (uint32_t)(((win + g) >> 6) & 3u);
     }
+    }
+    if (cur_seg != ~0ull) close_segment(cur_seg << 8);
 }
 
-// Far-line cache, junction counters, point counters, novel junctions -> the tables; all left empty.
-__device__ __forceinline__ void flush_caches(const CountTables& T, Lds& S, uint32_t tid, uint32_t lane, uint32_t wave, uint32_t& err) {
-    for (uint32_t e = tid; e < kLines * 16u; e += kThreads) {
-        const uint32_t slot = e >> 4, cell = e & 15u;               // a 16-lane row = one line = inside one segment
-        const uint32_t tag = S.ltag[slot];
-#ifndef K_NO_SKIP
-        if (__ballot(tag != kEmpty) == 0ull) continue;              // (none of the wave's four lines is claimed)
-#endif
+// counters of a direct-mapped cache -> a [2][n_rows] table
+template <uint32_t N>
+__device__ __forceinline__ void flush_cache(uint32_t* tags, uint32_t (*cnt)[N], uint16_t* list, uint32_t* list_n, uint32_t* table, uint64_t n_rows, uint32_t lane) {
+    const uint32_t n = *list_n;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t e = list[i];
+        const uint32_t row = tags[e];
+        const uint32_t c0 = cnt[0][e], c1 = cnt[1][e];
+        if (c0) add_u32(table + row, c0);
+        if (c1) add_u32(table + n_rows + row, c1);
+        tags[e] = kEmpty; cnt[0][e] = 0; cnt[1][e] = 0;
+    }
+    if (lane == 0u && n) *list_n = 0;
+}
+
+__device__ __forceinline__ void flush_queue(const CountTables& T, Lds& S, uint32_t lane) {
+    const uint32_t n = S.oq_n < kOQ ? S.oq_n : kOQ;
+    for (uint32_t e = lane; e < n; e += 64u) oq_apply(T, S.oq[e]);
+    if (lane == 0u && n) S.oq_n = 0;
+}
+
+// Far-line cache, junction / point / ROI counters, novel junctions -> the tables; all left empty.
+// (qb: the slice of the record buffer reserved for the nh + nq novel-junction records, in lane 0 — reserved by the caller
+//  before its other atomics, so that the wait for the returned value is one round trip)
+__device__ __forceinline__ void flush_caches(const CountTables& T, Lds& S, uint32_t lane, uint32_t& err, unsigned long long qb, uint32_t nq, uint32_t nh,
+                                             uint32_t* s_cstat_local) {
+    const uint32_t n_lines = S.ll_n;
+    for (uint32_t e0 = 0; e0 < n_lines; e0 += 4u) {                 // the claimed lines, four per step
+        const uint32_t li = e0 + (lane >> 4), cell = lane & 15u;    // a 16-lane row = one line = inside one segment
+        const uint32_t slot = li < n_lines ? S.llist[li] : kLines;
+        const uint32_t tag = li < n_lines ? S.ltag[slot] : kEmpty;
+        CSTAT(2, 1u);
         const int32_t v = tag != kEmpty ? S.lcnt[slot][cell] : 0;
         const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
         const int32_t v1 = (v - v0) >> 16;
         const uint64_t c = ((uint64_t)tag << 4) + cell;
         if (v) {
-#ifndef K_DIAG_NO_FLUSH_ATOMICS
-            if (v0) __hip_atomic_fetch_add(T.diff + c, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v1) __hip_atomic_fetch_add(T.diff + T.plane_stride + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef K_DIAG_NO_ATOMICS
+            if (v0) __hip_atomic_fetch_add(gp(T.diff) + c, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v1) __hip_atomic_fetch_add(gp(T.diff) + T.plane_stride + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
             S.lcnt[slot][cell] = 0;
         }
         const int32_t sp = row_sum_dpp(v);
-        const int32_t s0 = (int32_t)(int16_t)(uint16_t)(sp & 0xffff), s1 = (sp - s0) >> 16;
+        // (cell 15 holds the row's sums: it adds strand 0's, cell 14 strand 1's — one instruction)
+        const int32_t spn = (int32_t)__builtin_amdgcn_update_dpp(0, sp, 0x101, 0xf, 0xf, true);     // row_shl:1: cell 14 gets cell 15's sums
+        if (cell >= 14u && tag != kEmpty) {
+            const uint32_t dir = 15u - cell;
+            const int32_t t = dir ? spn : sp;
+            const int32_t t0 = (int32_t)(int16_t)(uint16_t)(t & 0xffff), t1 = (t - t0) >> 16;
+            const int32_t val = dir ? t1 : t0;
+            if (val) seg_add(T, dir, c, val);
+        }
         if (cell == 15u && tag != kEmpty) {
-#ifndef K_DIAG_NO_FLUSH_ATOMICS
-            if (s0) seg_add(T, 0u, c, s0);
-            if (s1) seg_add(T, 1u, c, s1);
-#endif
             // (a claimed line is marked for both strands whatever it holds: marking too much only costs the clear a line)
-            *reinterpret_cast<uint16_t*>(T.dirty + ((uint64_t)tag << 1)) = 0x0101u;
+#ifndef K_DIAG_NO_ATOMICS
+            *reinterpret_cast<AS1 uint16_t*>(gp(T.dirty) + ((uint64_t)tag << 1)) = 0x0101u;
+#endif
             S.ltag[slot] = kEmpty;          // (the row's 16 lanes have read the tag: same wave, program order)
         }
     }
-    for (uint32_t e = tid; e < kJCache; e += kThreads) {
-        const uint32_t row = S.jtag[e];
-        if (row != kEmpty) {
-            const uint32_t c0 = S.jcnt[0][e], c1 = S.jcnt[1][e];
-#ifndef K_DIAG_NO_FLUSH_ATOMICS
-            if (c0) atomicAdd(&T.known_cnt[row], c0);
-            if (c1) atomicAdd(&T.known_cnt[(uint64_t)T.n_kj + row], c1);
-#endif
-            S.jtag[e] = kEmpty; S.jcnt[0][e] = 0; S.jcnt[1][e] = 0;
-        }
-    }
-    for (uint32_t e = tid; e < kPCache; e += kThreads) {
-        const uint32_t pi = S.ptag[e];
-        if (pi != kEmpty) {
-            const uint32_t c0 = S.pcnt[0][e], c1 = S.pcnt[1][e];
-            const uint32_t row = T.sp_row[pi];
-            if (c0) atomicAdd(&T.sp_cnt[row], c0);
-            if (c1) atomicAdd(&T.sp_cnt[(uint64_t)T.n_sp + row], c1);
-            S.ptag[e] = kEmpty; S.pcnt[0][e] = 0; S.pcnt[1][e] = 0;
-        }
-    }
-    if (wave == 0u) {
-        // records of the slice so far: the merged table first (compacted with ballots), then the queue (weight 1)
-        const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ, nh = S.nh_n;
+    if (lane == 0u && n_lines) S.ll_n = 0;
+    flush_cache<kJCache>(S.jtag, S.jcnt, S.jlist, &S.jl_n, T.known_cnt, T.n_kj, lane);
+    flush_cache<kPCache>(S.ptag, S.pcnt, S.plist, &S.pl_n, T.sp_cnt, T.n_sp, lane);
+    flush_cache<kRCache>(S.rtag, S.rcnt, S.rlist, &S.rl_n, T.roi_cnt, T.n_roi, lane);
+    {
+        // novel-junction records: the merged table first (compacted with ballots), then the queue (weight 1)
         if (nq + nh) {
-            unsigned long long qb = 0;
-            if (lane == 0u) qb = atomicAdd(T.junc_count, (unsigned long long)(nq + nh));
             qb = __shfl(qb, 0);
             uint32_t at = 0;
 #pragma unroll
@@ -369,13 +490,13 @@ __device__ __forceinline__ void flush_caches(const CountTables& T, Lds& S, uint3
                 const uint64_t occ = __ballot(k != kEmpty64);
                 if (k != kEmpty64) {
                     const unsigned long long slot = qb + at + (unsigned long long)__popcll(occ & ((1ull << lane) - 1ull));
-                    if (slot < T.junc_capacity) { T.junc_keys[slot] = k; T.junc_w[slot] = w; } else err |= ERR_JUNC_CAPACITY;
+                    if (slot < T.junc_capacity) { gp(T.junc_keys)[slot] = k; gp(T.junc_w)[slot] = w; } else err |= ERR_JUNC_CAPACITY;
                     S.nh_key[e0 + lane] = kEmpty64; S.nh_cnt[e0 + lane] = 0;
                 }
                 at += (uint32_t)__popcll(occ);
             }
             for (uint32_t e = lane; e < nq; e += 64u) {
-                if (qb + nh + e < T.junc_capacity) { T.junc_keys[qb + nh + e] = S.nq[e]; T.junc_w[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
+                if (qb + nh + e < T.junc_capacity) { gp(T.junc_keys)[qb + nh + e] = S.nq[e]; gp(T.junc_w)[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
             }
             if (lane == 0u) { S.nq_n = 0; S.nh_n = 0; }
         }
@@ -403,8 +524,12 @@ __global__ __launch_bounds__(256) void chunk_origin_kernel(CountTables T, BatchD
     T.chunk_origin[c] = o;
 }
 
-__global__ __launch_bounds__(kThreads, K_WGS_PER_CU) void count_kernel(CountTables T, BatchDev B) {
+// the count kernel's table block in device memory (launch_count)
+__global__ void store_tables_kernel(CountTables T, CountTables* dst) { *dst = T; }
+
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const CountTables* __restrict__ Tp, BatchDev B) {
     __shared__ __align__(16) Lds S;
+    const CountTables& T = *Tp;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t k = tid; k < kChrBins; k += kThreads) S.chr[k] = 0;
     for (uint32_t k = tid; k < kWin + 64u; k += kThreads) S.tile[k] = 0;
@@ -412,275 +537,330 @@ __global__ __launch_bounds__(kThreads, K_WGS_PER_CU) void count_kernel(CountTabl
     for (uint32_t k = tid; k < (kLines + 1u) * 16u; k += kThreads) S.lcnt[k >> 4][k & 15u] = 0;
     for (uint32_t k = tid; k < kJCache; k += kThreads) { S.jtag[k] = kEmpty; S.jcnt[0][k] = 0; S.jcnt[1][k] = 0; }
     for (uint32_t k = tid; k < kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
+    for (uint32_t k = tid; k < kRCache; k += kThreads) { S.rtag[k] = kEmpty; S.rcnt[0][k] = 0; S.rcnt[1][k] = 0; }
     for (uint32_t k = tid; k < kNovelH; k += kThreads) { S.nh_key[k] = kEmpty64; S.nh_cnt[k] = 0; }
-    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.wmax[0] = 0; S.wmax[1] = 0; }
+    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.oq_n = 0; S.wmax[0] = 0; S.wmax[1] = 0; S.ll_n = 0; S.jl_n = 0; S.pl_n = 0; S.rl_n = 0; }
+    for (uint32_t k = tid; k < kChrTab; k += kThreads) S.chrtab[k] = k < T.n_chr ? ((const AS1 u32x4*)T.chr_rec)[k] : u32x4{0u, 0u, 0u, 0u};
 
     uint32_t err = 0;
 #ifdef COUNT_PROF
+    const bool prof_on = wave == 0u || wave == kWorkers - 1u || wave == kWorkers;
     unsigned long long prof_t = wall_clock64();
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
     const uint32_t n_slices = (n_chunks + kSlice - 1u) / kSlice;
-    // the columns of a chunk's fragments and the chunk's block range: loaded one chunk ahead, under the block phase
-    struct FragCols { uint32_t chr, fs, fe, o0, o1, flg, kb0, kb1; };
-    auto load_frag = [&](uint32_t c) -> FragCols {
-        FragCols r;
-        const uint32_t f0 = c * kChunk, f = f0 + tid;
-        const uint32_t fc = f < B.n_frag ? f : B.n_frag - 1u;
-        r.chr = B.frag_chr[fc]; r.fs = B.frag_start[fc]; r.fe = B.frag_end[fc];
-        r.o0 = B.frag_blk_off[fc]; r.o1 = B.frag_blk_off[fc + 1u]; r.flg = B.frag_flags[fc];
+    const AS1 unsigned long long* origin = gp((const unsigned long long*)T.chunk_origin);
+    // block range of a chunk (clamped: the offsets of a device-resident batch are not trusted)
+    auto chunk_blocks = [&](uint32_t c, uint32_t& kb0, uint32_t& kb1) {
+        const uint32_t f0 = c * kChunk;
         const uint32_t f_end = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
-        r.kb0 = B.frag_blk_off[f0]; r.kb1 = B.frag_blk_off[f_end];
-        return r;
+        kb0 = B.frag_blk_off[f0]; kb1 = B.frag_blk_off[f_end];
+        kb0 = kb0 < B.n_blk ? kb0 : B.n_blk;
+        kb1 = kb1 < B.n_blk ? kb1 : B.n_blk;
+        if (kb1 < kb0) kb1 = kb0;
     };
-    for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
-        const uint32_t c0 = slice * kSlice;
-        const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
-        unsigned long long win = 0;     // window = plane positions [win, win + kWin); uniform over the workgroup, like the next three
-        uint32_t wtop = 0;              // cells of win + [0, wtop) may be non-zero
-        uint32_t ev_since = 0;          // upper bound of the events added since everything was last flushed
-        uint32_t since_flush = 0;       // chunks since the caches were last flushed
-        FragCols fc_next = load_frag(c0);
-#ifdef K_SLICE_BARRIER
-        wg_barrier();
-#endif
-        for (uint32_t i = 0; i <= nc; i++) {
-            CPROF(5);
-            wg_barrier();            // ---- the block phase of chunk i - 1 is over (i = 0: the LDS is initialised / flushed) ----
-            CPROF(0);
-            wtop = umax(wtop, S.wmax[(i + 1u) & 1u]);
-#ifdef K_DIAG_FULL_WTOP
-            wtop = kWin;
-#endif
-            const bool last = i == nc;
-            const unsigned long long nw = last ? kNoWin : T.chunk_origin[c0 + i];
-            if (tid == 0) S.wmax[i & 1u] = 0;
 
-            // ---------------- the window follows the chunks; the caches are flushed every few chunks ----------------
-            {
+    uint32_t s_cstat_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (used by the diagnostic build only)
+    if (wave >= kWorkers) {
+        // ======================= the flusher waves =======================
+        // (one flusher does everything; of two, the first takes the window and the queue, the second the caches: no word
+        //  of LDS is written by both)
+        const bool do_win = wave == kWorkers, do_cch = wave == kWorkers + kFlushers - 1u;
+        for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+            const uint32_t c0 = slice * kSlice;
+            const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
+            unsigned long long win = 0;     // window = plane positions [win, win + kWin)
+            uint32_t wtop = 0;              // cells of win + [0, wtop) may be non-zero
+            uint32_t ev_since = 0;          // upper bound of the events added since everything was last flushed
+            uint32_t since_flush = 0;       // chunks since the caches were last flushed
+            for (uint32_t i = 0; i <= nc; i++) {
+                CPROF(3);
+                wg_barrier();               // ---- the block phase of chunk i - 1 is over (i = 0: the LDS is initialised) ----
+                CPROF(0);
+                wtop = umax(wtop, S.wmax[(i + 1u) & 1u]);      // (i = 0: may be the previous slice's; too large does no harm)
+                const bool last = i == nc;
+                const unsigned long long nw = last ? kNoWin : origin[c0 + i];
+                if (lane == 0u && do_win) S.wmax[i & 1u] = 0;
                 const bool ev_full = ev_since > kEvFlush;
                 bool jump = false;
                 uint32_t scroll = 0;
                 if (nw != kNoWin) {
                     if (nw < win || nw - win >= kWin) jump = true; else scroll = (uint32_t)(nw - win);
                 }
+                since_flush++;
+                const bool do_caches = last || ev_full || since_flush >= kFlushEvery;
+                unsigned long long qb = 0;
+                uint32_t nq = 0, nh = 0;
+                if (do_caches && do_cch) {
+                    nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ; nh = S.nh_n;
+                    if (lane == 0u && nq + nh) qb = __hip_atomic_fetch_add(gp(T.junc_count), (unsigned long long)(nq + nh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // the window follows the chunks
                 if (last || ev_full || jump) {
-                    flush_window(T, S, win, wtop, lane, wave);
+                    if (do_win) flush_window(T, S, win, wtop, lane, s_cstat_local);
                     wtop = 0;
+                    CSTAT(4, jump ? 1u : 0u);
                 } else if (scroll) {
-                    flush_window(T, S, win, scroll < wtop ? scroll : wtop, lane, wave);
+                    if (do_win) flush_window(T, S, win, scroll < wtop ? scroll : wtop, lane, s_cstat_local);
                     wtop = wtop > scroll ? wtop - scroll : 0u;
                 }
                 if (nw != kNoWin) win = nw;
-                since_flush++;
-                if (last || ev_full || since_flush >= kFlushEvery) {
-                    flush_caches(T, S, tid, lane, wave, err);
+                if (do_win) {
+                    CSTAT(3, S.oq_n); CSTAT(6, 1u);
+                    flush_queue(T, S, lane);
+                }
+                if (do_caches) {
+                    if (do_cch) {
+                        CSTAT(5, 1u);
+                        flush_caches(T, S, lane, err, qb, nq, nh, s_cstat_local);
+                    }
                     since_flush = 0;
                 }
                 if (last || ev_full) ev_since = 0;
+                CPROF(1);
+                if (last) break;            // (the slice's accumulators are empty again)
+                uint32_t kb0, kb1;
+                chunk_blocks(c0 + i, kb0, kb1);
+                if (kb1 - kb0 <= kWinMaxBlocks) ev_since += 2u * (kb1 - kb0);
+                CPROF(2);
+                wg_barrier();               // ---- the workers start the block phase ----
+                for (uint32_t t0 = kb0 + kTile; t0 < kb1; t0 += kTile) { wg_barrier(); wg_barrier(); }     // (their owner tiles)
             }
-            CPROF(1);
-            if (last) break;            // (the slice's accumulators are empty again)
+        }
+    } else {
+        // ======================= the worker waves =======================
+        const AS1 u32x4* cell_s = (const AS1 u32x4*)T.cell_s;
+        const AS1 u32x4* cell_e = (const AS1 u32x4*)T.cell_e;
+        const AS1 u32x4* jhash = (const AS1 u32x4*)T.jhash;
+        const AS1 u32x4* chr_rec = (const AS1 u32x4*)T.chr_rec;
+        const AS1 u32x4* roi_bkt = (const AS1 u32x4*)T.roi_bkt;
+        const uint32_t jh_mask = T.jh_mask, n_chr = T.n_chr, n_roi_dev = T.n_roi_dev, junc_min_flank = T.junc_min_flank, sp_min_len = T.sp_min_len;
+        // the columns of a chunk's fragments: loaded one chunk ahead
+        struct Cols { uint32_t bs, bl, rd; };
+        auto load_cols = [&](uint32_t k) -> Cols {
+            Cols c = {0u, 0u, 0u};
+            if (B.n_blk == 0u) return c;            // (fragments without any block: the arrays may not exist)
+            const uint32_t kc = k < B.n_blk ? k : B.n_blk - 1u;
+            c.bs = B.blk_start[kc]; c.bl = B.blk_len[kc]; c.rd = B.blk_read[kc];
+            return c;
+        };
+        struct FragCols { uint32_t chr, fs, fe, o0, o1, flg; };
+        auto load_frag = [&](uint32_t c) -> FragCols {
+            FragCols r;
+            const uint32_t f = c * kChunk + tid;
+            const uint32_t fc = f < B.n_frag ? f : B.n_frag - 1u;
+            r.chr = B.frag_chr[fc]; r.fs = B.frag_start[fc]; r.fe = B.frag_end[fc];
+            r.o0 = B.frag_blk_off[fc]; r.o1 = B.frag_blk_off[fc + 1u]; r.flg = B.frag_flags[fc];
+            return r;
+        };
+        for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+            const uint32_t c0 = slice * kSlice;
+            const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
+            unsigned long long win = 0;
+            FragCols fc_next = load_frag(c0);
+            for (uint32_t i = 0; i <= nc; i++) {
+                CPROF(3);
+                wg_barrier();               // ---- the block phase of chunk i - 1 is over ----
+                CPROF(0);
+                if (i == nc) break;         // (the flusher empties the slice's accumulators)
+                const unsigned long long nw = origin[c0 + i];
+                if (nw != kNoWin) win = nw;
 
-            // ---------------- F. fragment phase of chunk i ----------------
-            const uint32_t f0 = (c0 + i) * kChunk, f = f0 + tid;
-            const bool in = f < B.n_frag;
-            const uint32_t chr = fc_next.chr, fs = fc_next.fs, fe = fc_next.fe, o0 = fc_next.o0, o1 = fc_next.o1, flg = fc_next.flg;
-            uint32_t kb0 = fc_next.kb0, kb1 = fc_next.kb1;
-            // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here): inside
-            // the array's bounds, non-decreasing, spanning [0, n_blk].  Clamped, they address nothing out of bounds.
-            if (in && (o0 > B.n_blk || o1 > B.n_blk || o1 < o0 || (f == 0u && o0 != 0u) || (f == B.n_frag - 1u && o1 != B.n_blk))) err |= ERR_CSR;
-            kb0 = kb0 < B.n_blk ? kb0 : B.n_blk;
-            kb1 = kb1 < B.n_blk ? kb1 : B.n_blk;
-            if (kb1 < kb0) kb1 = kb0;
-            uint32_t o0c = o0 < B.n_blk ? o0 : B.n_blk, o1c = o1 < B.n_blk ? o1 : B.n_blk;
-            if (!in) { o0c = 0; o1c = 0; }
-            const bool chr_ok = in && chr < T.n_chr;
-            if (in && !chr_ok) err |= ERR_CHR_RANGE;
-            const uint4 rec = T.chr_rec[chr_ok ? chr : 0u];                // the table holds at least one entry
-            const bool counted = chr_ok && rec.w != 0u;
-            const uint64_t base = (uint64_t)rec.y << 32 | rec.x;
-            const uint32_t clen = rec.z;
-            const uint32_t dir = flg & 1u;
-            S.facts[tid] = counted ? make_uint2((uint32_t)(base >> 6) | (dir ? kFragDir : 0u) | kFragValid, clen) : make_uint2(0u, 0u);
-            // the owner entries of the fragment's blocks (first tile; the others below)
-            auto scatter = [&](uint32_t t0) {
-                for (uint32_t k = o0c > t0 ? o0c : t0; k < o1c && k - t0 <= kTile; k++)
-                    S.owner[k - t0] = (uint16_t)(tid | (k == o0c ? kOwnFirst : 0u) | (k + 1u == o1c ? kOwnLast : 0u));
-            };
-            scatter(kb0);
-            // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment
-            if (T.n_roi_dev) {
-                const bool extent_ok = counted && fs <= fe && fe <= clen;
+                // ---------------- F. fragment phase of chunk i ----------------
+                const uint32_t f = (c0 + i) * kChunk + tid;
+                const bool in = f < B.n_frag;
+                const uint32_t chr = fc_next.chr, fs = fc_next.fs, fe = fc_next.fe, o0 = fc_next.o0, o1 = fc_next.o1, flg = fc_next.flg;
+                uint32_t kb0, kb1;
+                chunk_blocks(c0 + i, kb0, kb1);
+                // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here): inside
+                // the array's bounds, non-decreasing, spanning [0, n_blk].  Clamped, they address nothing out of bounds.
+                if (in && (o0 > B.n_blk || o1 > B.n_blk || o1 < o0 || (f == 0u && o0 != 0u) || (f == B.n_frag - 1u && o1 != B.n_blk))) err |= ERR_CSR;
+                uint32_t o0c = o0 < B.n_blk ? o0 : B.n_blk, o1c = o1 < B.n_blk ? o1 : B.n_blk;
+                if (!in) { o0c = 0; o1c = 0; }
+                const bool chr_ok = in && chr < n_chr;
+                if (in && !chr_ok) err |= ERR_CHR_RANGE;
+                u32x4 rec = S.chrtab[chr_ok && chr < kChrTab ? chr : 0u];
+                if (chr_ok && chr >= kChrTab) rec = chr_rec[chr];
+                const bool counted = chr_ok && rec.w != 0u;
+                const uint64_t base = (uint64_t)rec.y << 32 | rec.x;
+                const uint32_t clen = rec.z;
+                const uint32_t dir = flg & 1u;
+                S.facts[tid] = counted ? make_uint2((uint32_t)(base >> 6) | (dir ? kFragDir : 0u) | kFragValid, clen) : make_uint2(0u, 0u);
+                // the owner entries of the fragment's blocks (first tile; the others below)
+                auto scatter = [&](uint32_t t0) {
+                    for (uint32_t k = o0c > t0 ? o0c : t0; k < o1c && k - t0 <= kTile; k++)
+                        S.owner[k - t0] = (uint16_t)(tid | (k == o0c ? kOwnFirst : 0u) | (k + 1u == o1c ? kOwnLast : 0u));
+                };
+                scatter(kb0);
+                // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment.  The record
+                // is requested here and looked at behind the barrier (the fragment phase waits for no load; and until then
+                // the caches and the queue are the flusher's)
+                const bool extent_ok = n_roi_dev != 0u && counted && fs <= fe && fe <= clen;
                 const uint64_t gfs = base + fs, gfe = base + fe;
-                const uint4 R = T.roi_bkt[extent_ok ? gfe >> kBucketShift : 0ull];
-                if (extent_ok && R.x < T.n_roi_dev) {
-                    uint32_t q = R.x;
-                    uint64_t rgs = (uint64_t)(R.w & 0xffffu) << 32 | R.y;
-                    const uint64_t rge = (uint64_t)(R.w >> 16) << 32 | R.z;
-                    bool have = true;
-                    if (rge < gfe) {              // several ROIs end inside the bucket before the fragment does
-                        q++;
-                        while (q < T.n_roi_dev && T.roi_gend[q] < gfe) q++;
-                        have = q < T.n_roi_dev;
-                        if (have) rgs = T.roi_gstart[q];
+                const u32x4 R = roi_bkt[extent_ok ? gfe >> kBucketShift : 0ull];
+                // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
+                unsigned long long chr_over = 0ull;      // (a reference beyond the LDS histogram: through the queue, behind the barrier)
+                {
+                    const uint32_t k = counted ? chr * 2u + dir : kEmpty;
+                    uint64_t todo = __ballot(k != kEmpty);
+                    while (todo) {
+                        const int lead = __ffsll((long long)todo) - 1;
+                        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)k, lead);
+                        const uint64_t same = __ballot(k == lk);
+                        if ((int)lane == lead) {
+                            const uint32_t n = (uint32_t)__popcll(same);
+                            if (lk < kChrBins) atomicAdd(&S.chr[lk], n);
+                            else chr_over = kOqRoi | 1ull << 60 | (unsigned long long)n << 32 | lk;
+                        }
+                        todo &= ~same;
                     }
-#ifndef K_DIAG_NO_ROI_ATOMICS
-                    if (have && rgs <= gfs) atomicAdd(&T.roi_cnt[(uint64_t)dir * T.n_roi + T.roi_idx[q]], 1u);
-#endif
                 }
-            }
-            // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
-            {
-                const uint32_t k = counted ? chr * 2u + dir : kEmpty;
-                uint64_t todo = __ballot(k != kEmpty);
-                while (todo) {
-                    const int lead = __ffsll((long long)todo) - 1;
-                    const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)k, lead);
-                    const uint64_t same = __ballot(k == lk);
-                    if ((int)lane == lead) {
-                        const uint32_t n = (uint32_t)__popcll(same);
-                        if (lk < kChrBins) atomicAdd(&S.chr[lk], n);
-                        else atomicAdd(&T.chr_cnt[lk], n);
-                    }
-                    todo &= ~same;
-                }
-            }
-#ifndef K_NO_PREFETCH
-            if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);      // (in flight under the block phase)
-#ifdef K_PREFETCH_WAIT
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#endif
-            CPROF(2);
-            wg_barrier();            // ---- facts and owners of chunk i are in place, the flushed cells are zero ----
-            CPROF(3);
+                if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);      // (in flight under the block phase)
+                // the block columns of the wave's first strides are requested in front of the barrier
+                Cols nxt[kBU];
+#pragma unroll
+                for (int u = 0; u < kBU; u++) nxt[u] = load_cols(kb0 + (wave + u * kWorkers) * kStride + lane);
+                CPROF(1);
+                wg_barrier();               // ---- facts and owners of chunk i are in place, the flushed cells are zero ----
+                CPROF(2);
 
-            // ---------------- B. block phase: one block per lane and stride of 63, kBU strides at once ----------------
-            const uint32_t nblk_c = kb1 - kb0;
-            const bool use_win = nblk_c <= kWinMaxBlocks;
-            if (use_win) ev_since += 2u * nblk_c;
-            const uint32_t win5 = (uint32_t)(win >> 5);
-            uint32_t wmax = 0;
-            struct Cols { uint32_t bs, bl, rd; };
-            auto load_cols = [&](uint32_t k) -> Cols {
-                const uint32_t kc = k < B.n_blk ? k : B.n_blk - 1u;      // (n_blk > 0 wherever this runs)
-                Cols c;
-                c.bs = B.blk_start[kc]; c.bl = B.blk_len[kc]; c.rd = B.blk_read[kc];
-                return c;
-            };
-            for (uint32_t t0 = kb0; t0 < kb1;) {
-                const uint32_t tile_n = kb1 - t0 < kTile ? kb1 - t0 : kTile;
-                const uint32_t n_str = (tile_n + kStride - 1u) / kStride;
-                for (uint32_t s0 = wave; s0 < n_str; s0 += kWaves * kBU) {
-                    // (a stride beyond the tile's last does nothing: `here` is false in every lane)
-                    Cols cur[kBU];
-                    uint32_t ti[kBU], ow[kBU], fb[kBU], clen_b[kBU], be[kBU], bdir[kBU];
-                    bool here[kBU], own[kBU], ok[kBU];
-                    uint4 rs[kBU], re[kBU], je[kBU];
-#pragma unroll
-                    for (int u = 0; u < kBU; u++) {
-                        ti[u] = (s0 + u * kWaves) * kStride + lane;
-                        cur[u] = load_cols(t0 + ti[u]);
-                        here[u] = t0 + ti[u] < kb1 && ti[u] <= kTile;        // the block exists and has an owner entry in this tile
-                        own[u] = here[u] && lane < kStride && ti[u] < tile_n;
-                        ow[u] = S.owner[here[u] ? ti[u] : 0u];
+                {
+                    uint32_t q = R.z & 0x0fffffffu;
+                    if (extent_ok && q < n_roi_dev) {
+                        uint64_t rgs = (uint64_t)((R.z >> 28) & 3u) << 32 | R.x;
+                        const uint64_t rge = (uint64_t)(R.z >> 30) << 32 | R.y;
+                        uint32_t row = R.w;
+                        bool have = true;
+                        if (rge < gfe) {              // several ROIs end inside the bucket before the fragment does
+                            q++;
+                            while (q < n_roi_dev && gp(T.roi_gend)[q] < gfe) q++;
+                            have = q < n_roi_dev;
+                            if (have) { rgs = gp(T.roi_gstart)[q]; row = gp(T.roi_idx)[q]; }
+                        }
+                        if (have && rgs <= gfs) cache_add<kRCache>(T, S, S.rtag, S.rcnt, S.rlist, &S.rl_n, row, dir, kOqRoi);
                     }
+                }
+                if (chr_over) oq_push(T, S, chr_over);
+                // ---------------- B. block phase: one block per lane and stride of 63, kBU strides at once ----------------
+                const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
+                const uint32_t win5 = (uint32_t)(win >> 5);
+                uint32_t wmax = 0;
+                for (uint32_t t0 = kb0; t0 < kb1;) {
+                    const uint32_t tile_n = kb1 - t0 < kTile ? kb1 - t0 : kTile;
+                    const uint32_t n_str = (tile_n + kStride - 1u) / kStride;
+                    for (uint32_t s0 = wave; s0 < n_str; s0 += kWorkers * kBU) {
+                        // (a stride beyond the tile's last does nothing: `here` is false in every lane)
+                        Cols cur[kBU];
+                        uint32_t ti[kBU], ow[kBU], fb[kBU], clen_b[kBU], be[kBU], bdir[kBU];
+                        bool here[kBU], own[kBU], ok[kBU];
+                        u32x4 rs[kBU], re[kBU], je[kBU];
 #pragma unroll
-                    for (int u = 0; u < kBU; u++) {
-                        const uint2 fa = S.facts[ow[u] & 255u];
-                        fb[u] = here[u] ? fa.x : 0u; clen_b[u] = fa.y;
-                    }
+                        for (int u = 0; u < kBU; u++) {
+                            ti[u] = (s0 + u * kWorkers) * kStride + lane;
+                            cur[u] = nxt[u];
+                            nxt[u] = load_cols(t0 + ti[u] + kWorkers * kBU * kStride);        // (the next pass, requested now)
+                            here[u] = t0 + ti[u] < kb1 && ti[u] <= kTile;        // the block exists and has an owner entry in this tile
+                            own[u] = here[u] && lane < kStride && ti[u] < tile_n;
+                            ow[u] = S.owner[here[u] ? ti[u] : 0u];
+                        }
 #pragma unroll
-                    for (int u = 0; u < kBU; u++) {
-                        const uint32_t bs = cur[u].bs;
-                        be[u] = bs + cur[u].bl;
-                        const bool in_range = be[u] >= bs && be[u] <= clen_b[u];
-                        const bool valid = (fb[u] & kFragValid) != 0u;
-                        if (own[u] && valid && !in_range) err |= ERR_BLOCK_RANGE;
-                        ok[u] = valid && in_range;
-                        bdir[u] = (fb[u] & kFragDir) ? 1u : 0u;
-                        const uint32_t cbase = (fb[u] & kFragBaseMask) << 1;      // base >> 5
-                        // the two cell records: plane coordinates of start and end, point ranks of both range ends
-                        rs[u] = T.cell_s[ok[u] ? cbase + (bs >> kCellShift) : 0u];
-                        re[u] = T.cell_e[ok[u] ? cbase + (be[u] >> kCellShift) : 0u];
-                    }
-                    uint32_t bs1[kBU], span[kBU], klo[kBU], khi[kBU], slot[kBU];
-                    uint64_t gbe[kBU];
-                    bool has_next[kBU], jc[kBU];
+                        for (int u = 0; u < kBU; u++) {
+                            const uint2 fa = S.facts[ow[u] & kOwnMask];
+                            fb[u] = here[u] ? fa.x : 0u; clen_b[u] = fa.y;
+                        }
 #pragma unroll
-                    for (int u = 0; u < kBU; u++) {
-                        // the successor (next lane): junction to the right of the block — both flanks long enough, same read,
-                        // same fragment
-                        bs1[u] = from_next_lane(cur[u].bs);
-                        const uint32_t bl1 = from_next_lane(cur[u].bl), rd1 = from_next_lane(cur[u].rd);
-                        const bool ok1 = from_next_lane(ok[u] ? 1u : 0u) != 0u;
-                        has_next[u] = own[u] && ok[u] && !(ow[u] & kOwnLast) && ok1;
-                        jc[u] = has_next[u] && rd1 == cur[u].rd && cur[u].bl >= T.junc_min_flank && bl1 >= T.junc_min_flank;
-                        span[u] = bs1[u] - be[u];
-                        if (jc[u] && (bs1[u] < be[u] || span[u] >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[u] = false; }
-                        gbe[u] = ((uint64_t)(fb[u] & kFragBaseMask) << 6) + be[u];
-                        klo[u] = ((uint32_t)gbe[u] << kJuncSpanBits) | span[u];
-                        khi[u] = (uint32_t)(gbe[u] >> (32 - kJuncSpanBits));
-                        slot[u] = junction_hash(klo[u], khi[u]) & T.jh_mask;
-                        je[u] = T.jhash[jc[u] ? slot[u] : 0u];
-                        asm volatile("" : "+v"(je[u].z));       // (the row comes with the key, not in a second load behind the compare)
-                    }
+                        for (int u = 0; u < kBU; u++) {
+                            const uint32_t bs = cur[u].bs;
+                            be[u] = bs + cur[u].bl;
+                            const bool in_range = be[u] >= bs && be[u] <= clen_b[u];
+                            const bool valid = (fb[u] & kFragValid) != 0u;
+                            if (own[u] && valid && !in_range) err |= ERR_BLOCK_RANGE;
+                            ok[u] = valid && in_range;
+                            bdir[u] = (fb[u] & kFragDir) ? 1u : 0u;
+                            const uint32_t cbase = (fb[u] & kFragBaseMask) << 1;      // base >> 5
+                            // the two cell records: plane coordinates of start and end, point ranks of both range ends
+                            rs[u] = cell_s[ok[u] ? cbase + (bs >> kCellShift) : 0u];
+                            re[u] = cell_e[ok[u] ? cbase + (be[u] >> kCellShift) : 0u];
+                        }
+                        uint32_t bs1[kBU], span[kBU], klo[kBU], khi[kBU], slot[kBU], rsz1[kBU];
+                        uint64_t gbe[kBU];
+                        bool has_next[kBU], jc[kBU];
 #pragma unroll
-                    for (int u = 0; u < kBU; u++) {
-                        const uint32_t bs = cur[u].bs, bl = cur[u].bl;
-                        const uint32_t rsz1 = from_next_lane(rs[u].z);
-                        // known junction?  (the probe continues only past a slot another key holds: load <= 1/32)
-                        bool hit = jc[u] && je[u].x == klo[u] && je[u].y == khi[u];
-                        {
-                            bool more = jc[u] && !hit && (je[u].x & je[u].y) != kEmpty;
-                            while (more) {
-                                slot[u] = (slot[u] + 1u) & T.jh_mask;
-                                je[u] = T.jhash[slot[u]];
-                                hit = je[u].x == klo[u] && je[u].y == khi[u];
-                                more = !hit && (je[u].x & je[u].y) != kEmpty;
+                        for (int u = 0; u < kBU; u++) {
+                            // the successor (next lane): junction to the right of the block — both flanks long enough, same read,
+                            // same fragment
+                            bs1[u] = from_next_lane(cur[u].bs);
+                            const uint32_t bl1 = from_next_lane(cur[u].bl), rd1 = from_next_lane(cur[u].rd);
+                            const bool ok1 = from_next_lane(ok[u] ? 1u : 0u) != 0u;
+                            has_next[u] = own[u] && ok[u] && !(ow[u] & kOwnLast) && ok1;
+                            jc[u] = has_next[u] && rd1 == cur[u].rd && cur[u].bl >= junc_min_flank && bl1 >= junc_min_flank;
+                            span[u] = bs1[u] - be[u];
+                            if (jc[u] && (bs1[u] < be[u] || span[u] >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[u] = false; }
+                            gbe[u] = ((uint64_t)(fb[u] & kFragBaseMask) << 6) + be[u];
+                            klo[u] = ((uint32_t)gbe[u] << kJuncSpanBits) | span[u];
+                            khi[u] = (uint32_t)(gbe[u] >> (32 - kJuncSpanBits));
+                            slot[u] = junction_hash(klo[u], khi[u]) & jh_mask;
+                            je[u] = jhash[jc[u] ? slot[u] : 0u];
+                            asm volatile("" : "+v"(je[u].z));       // (the row comes with the key, not in a second load behind the compare)
+                        }
+#pragma unroll
+                        for (int u = 0; u < kBU; u++) rsz1[u] = from_next_lane(rs[u].z);
+#pragma unroll
+                        for (int u = 0; u < kBU; u++) {
+                            const uint32_t bs = cur[u].bs, bl = cur[u].bl;
+                            // known junction?  (the probe continues only past a slot another key holds: load <= 1/32)
+                            bool hit = jc[u] && je[u].x == klo[u] && je[u].y == khi[u];
+                            {
+                                bool more = jc[u] && !hit && (je[u].x & je[u].y) != kEmpty;
+                                while (more) {
+                                    slot[u] = (slot[u] + 1u) & jh_mask;
+                                    je[u] = jhash[slot[u]];
+                                    hit = je[u].x == klo[u] && je[u].y == khi[u];
+                                    more = !hit && (je[u].x & je[u].y) != kEmpty;
+                                }
+                            }
+                            // JunctionCount: a known junction's counter also stands for the read's two difference events here
+                            if (hit) cache_add<kJCache>(T, S, S.jtag, S.jcnt, S.jlist, &S.jl_n, je[u].z, bdir[u], kOqKnown);
+                            if (jc[u] && !hit) novel_add(T, S, (gbe[u] << kJuncLeftShift) | ((unsigned long long)span[u] << 1) | bdir[u], lane, err);
+                            // CoverageBlocks / FragmentsMap: the block's end, its successor's start (unless the junction between
+                            // them was counted on a known junction), and its own start if it opens the fragment
+                            depth_event(T, S, win5, use_win, re[u].z, be[u] & 31u, bdir[u], -1, own[u] && ok[u] && !hit, lane, wmax);
+                            depth_event(T, S, win5, use_win, rsz1[u], bs1[u] & 31u, bdir[u], 1, has_next[u] && !hit, lane, wmax);
+                            depth_event(T, S, win5, use_win, rs[u].z, bs & 31u, bdir[u], 1, own[u] && ok[u] && (ow[u] & kOwnFirst) != 0u, lane, wmax);
+                            // SpansPoint: the points in [bs + sp_lo_add, be - sp_hi_sub] are n1 - n0 points with consecutive rows
+                            if (own[u] && ok[u] && bl > sp_min_len) {
+                                const uint32_t skip = (uint32_t)__popc(rs[u].y & ((1u << (bs & 31u)) - 1u));
+                                const uint32_t n0 = rs[u].x + skip;
+                                const uint32_t n1 = re[u].x + (uint32_t)__popc(re[u].y & ((1u << (be[u] & 31u)) - 1u));
+                                const uint32_t row0 = rs[u].w + skip;
+                                for (uint32_t p = n0; p < n1; p++) cache_add<kPCache>(T, S, S.ptag, S.pcnt, S.plist, &S.pl_n, row0 + (p - n0), bdir[u], kOqPoint);
                             }
                         }
-                        // JunctionCount: a known junction's counter also stands for the read's two difference events here
-                        if (hit) junction_add(T, S, je[u].z, bdir[u]);
-                        if (jc[u] && !hit) novel_add(T, S, (gbe[u] << kJuncLeftShift) | ((unsigned long long)span[u] << 1) | bdir[u], lane, err);
-                        // CoverageBlocks / FragmentsMap: the block's end, its successor's start (unless the junction between
-                        // them was counted on a known junction), and its own start if it opens the fragment
-                        depth_event(T, S, win5, use_win, re[u].z, be[u] & 31u, bdir[u], -1, own[u] && ok[u] && !hit, lane, wmax);
-                        depth_event(T, S, win5, use_win, rsz1, bs1[u] & 31u, bdir[u], 1, has_next[u] && !hit, lane, wmax);
-                        depth_event(T, S, win5, use_win, rs[u].z, bs & 31u, bdir[u], 1, own[u] && ok[u] && (ow[u] & kOwnFirst) != 0u, lane, wmax);
-                        // SpansPoint: the points in [bs + sp_lo_add, be - sp_hi_sub] = ranks n0 .. n1 - 1
-                        if (own[u] && ok[u] && bl > T.sp_min_len) {
-                            const uint32_t n0 = rs[u].x + (uint32_t)__popc(rs[u].y & ((1u << (bs & 31u)) - 1u));
-                            const uint32_t n1 = re[u].x + (uint32_t)__popc(re[u].y & ((1u << (be[u] & 31u)) - 1u));
-                            for (uint32_t p = n0; p < n1; p++) point_add(T, S, p, bdir[u]);
-                        }
+                    }
+                    t0 += kTile;
+                    if (t0 < kb1) {         // a chunk with more blocks than one tile holds: the next tile's owners
+                        wg_barrier();
+                        scatter(t0);
+#pragma unroll
+                        for (int u = 0; u < kBU; u++) nxt[u] = load_cols(t0 + (wave + u * kWorkers) * kStride + lane);
+                        wg_barrier();
                     }
                 }
-                t0 += kTile;
-                if (t0 < kb1) {         // a chunk with more blocks than one tile holds: the next tile's owners
-                    wg_barrier();
-                    scatter(t0);
-                    wg_barrier();
-                }
+                wmax = wave_max_dpp(wmax);
+                if (lane == 63u && wmax) atomicMax(&S.wmax[i & 1u], wmax);
             }
-            wmax = wave_max_dpp(wmax);
-            if (lane == 63u && wmax) atomicMax(&S.wmax[i & 1u], wmax);
-#ifdef K_NO_PREFETCH
-            if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);
-#endif
-            CPROF(4);
         }
     }
 #ifdef COUNT_PROF
-    if (lane == 0u && (wave == 0u || wave == 3u) && blockIdx.x < 2048u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][wave ? 1 : 0][k] = prof_acc[k];
+    if (lane == 0u && wave >= kWorkers) for (int k = 0; k < 8; k++) atomicAdd(&g_cstat[k], (unsigned long long)s_cstat_local[k]);
+    if (lane == 0u && prof_on && blockIdx.x < 2048u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][wave == 0u ? 0 : (wave == kWorkers ? 2 : 1)][k] = prof_acc[k];
 #endif
-    if (err) atomicOr(T.err_flags, err);
+    if (err) __hip_atomic_fetch_or(gp(T.err_flags), err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wg_barrier();
     for (uint32_t k = tid; k < kChrBins; k += kThreads) {
         const uint32_t v = S.chr[k];
-        if (v && (k >> 1) < T.n_chr) atomicAdd(&T.chr_cnt[k], v);
+        if (v && (k >> 1) < T.n_chr) add_u32(T.chr_cnt + k, v);
     }
 }
 
@@ -713,10 +893,10 @@ __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T
             if (!c) continue;
             __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cl, -c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(T.diff + (uint64_t)dir * T.plane_stride + cr, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seg_add(T, dir, cl, -c);
-            seg_add(T, dir, cr, c);
-            mark_dirty(T, dir, cl);
-            mark_dirty(T, dir, cr);
+            __hip_atomic_fetch_add(T.seg_sum + (uint64_t)dir * (T.plane_stride >> kSegShift) + (cl >> kSegShift), (uint32_t)-c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(T.seg_sum + (uint64_t)dir * (T.plane_stride >> kSegShift) + (cr >> kSegShift), (uint32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T.dirty[((cl >> 4) << 1) + dir] = 1;
+            T.dirty[((cr >> 4) << 1) + dir] = 1;
         }
     }
 #pragma unroll
@@ -760,10 +940,10 @@ __global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* __restrict__
 }
 
 // The two cell tables (kernels.h).  One thread per cell: the rank of the cell's first shifted position among the sorted
-// points (binary search), the points of its 32 shifted positions as bits, and the plane word.
-__global__ __launch_bounds__(256) void build_cells_kernel(const uint64_t* __restrict__ points, uint32_t n_points, const uint32_t* __restrict__ pmap,
-                                                          uint64_t n_cells, int32_t shift_s, int32_t shift_e, uint4* __restrict__ cell_s,
-                                                          uint4* __restrict__ cell_e) {
+// points (binary search), the points of its 32 shifted positions as bits, the plane word and the counter row of the first.
+__global__ __launch_bounds__(256) void build_cells_kernel(const uint64_t* __restrict__ points, const uint32_t* __restrict__ rows, uint32_t n_points,
+                                                          const uint32_t* __restrict__ pmap, uint64_t n_cells, int32_t shift_s, int32_t shift_e,
+                                                          uint4* __restrict__ cell_s, uint4* __restrict__ cell_e) {
     const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (c >= n_cells) return;
     uint32_t word;
@@ -785,17 +965,19 @@ __global__ __launch_bounds__(256) void build_cells_kernel(const uint64_t* __rest
         }
         uint32_t bits = 0;
         for (uint32_t j = a; j < n_points && (long long)points[j] < lo + 32; j++) bits |= 1u << (uint32_t)((long long)points[j] - lo);
-        (t == 0 ? cell_s : cell_e)[c] = make_uint4(a, bits, word, 0u);
+        (t == 0 ? cell_s : cell_e)[c] = make_uint4(a, bits, word, a < n_points ? rows[a] : 0u);
     }
 }
 
 }   // namespace
 
-void launch_build_cells(const uint64_t* points, uint32_t n_points, const uint32_t* pmap, uint64_t n_cells, int32_t shift_s, int32_t shift_e,
-                        uint4* cell_s, uint4* cell_e, hipStream_t s) {
+uint32_t count_chunk_fragments() { return kChunk; }
+
+void launch_build_cells(const uint64_t* points, const uint32_t* rows, uint32_t n_points, const uint32_t* pmap, uint64_t n_cells, int32_t shift_s,
+                        int32_t shift_e, uint4* cell_s, uint4* cell_e, hipStream_t s) {
     if (!n_cells) return;
-    hipLaunchKernelGGL(build_cells_kernel, dim3((uint32_t)((n_cells + 255u) / 256u)), dim3(256), 0, s, points, n_points, pmap, n_cells, shift_s, shift_e,
-                       cell_s, cell_e);
+    hipLaunchKernelGGL(build_cells_kernel, dim3((uint32_t)((n_cells + 255u) / 256u)), dim3(256), 0, s, points, rows, n_points, pmap, n_cells, shift_s,
+                       shift_e, cell_s, cell_e);
 }
 
 void launch_known_junction_depth(const CountTables& T, hipStream_t s) {
@@ -813,25 +995,35 @@ void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride,
     hipLaunchKernelGGL(sparse_clear_kernel, dim3((uint32_t)(wgs < 512u ? wgs : 512u)), dim3(256), 0, s, planes, dirty, plane_stride, n_groups);
 }
 
-void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s) {
+void launch_count(const CountTables& T, CountTables* d_T, CountTables* shadow, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;
+    if (memcmp(&T, shadow, sizeof T) != 0) {
+        hipLaunchKernelGGL(store_tables_kernel, dim3(1), dim3(1), 0, s, T, d_T);
+        *shadow = T;
+    }
     const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
     const uint32_t n_slices = (n_chunks + kSlice - 1u) / kSlice;
     const uint32_t most = 256u * K_WGS_PER_CU;
+    const uint32_t blocks = n_slices < most ? n_slices : most;
     hipLaunchKernelGGL(chunk_origin_kernel, dim3((n_chunks + 255u) / 256u), dim3(256), 0, s, T, B, n_chunks);
-    hipLaunchKernelGGL(count_kernel, dim3(n_slices < most ? n_slices : most), dim3(kThreads), 0, s, T, B);
+    hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, d_T, B);
 #ifdef COUNT_PROF
     {
-        static uint32_t h[2048][2][8];
-        const uint32_t blocks = n_slices < most ? n_slices : most;
+        static uint32_t h[2048][3][8];
+        unsigned long long st[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cprof), sizeof h);
-        for (int w = 0; w < 2; w++) {
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_cstat), sizeof st);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cstat), zero, sizeof zero);
+        fprintf(stderr, "count_stat: chunks %llu, window steps looked at %llu, not empty %llu, line steps not empty %llu, queue entries %llu, jumps %llu, cache flushes %llu\n",
+                st[6], st[0], st[1], st[2], st[3], st[4], st[5]);
+        const char* who[3] = {"worker 0", "last worker", "flusher"};
+        for (int w = 0; w < 3; w++) {
             double a[8] = {0};
             for (uint32_t b = 0; b < blocks && b < 2048u; b++) for (int k = 0; k < 8; k++) a[k] += h[b][w][k];
             const double n = blocks < 2048u ? blocks : 2048u;
-            fprintf(stderr, "count_prof wave %d, 10 ns ticks per workgroup: wait at barrier 1 %.0f | flushes %.0f | fragment phase %.0f | wait at barrier 2 %.0f | block phase %.0f | loop overhead %.0f\n",
-                    w ? 3 : 0, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n);
+            fprintf(stderr, "count_prof %s, 10 ns ticks per workgroup: wait at barrier 1 %.0f | fragment phase / flushes %.0f | wait at barrier 2 %.0f | block phase / idle %.0f\n",
+                    who[w], a[0] / n, a[1] / n, a[2] / n, a[3] / n);
         }
     }
 #endif

@@ -153,6 +153,8 @@ struct irf_ctx {
     DevBuf<uint64_t> d_sp_gpos;                  // SpansPoint: the points' full coordinates, sorted (input of the cell tables)
     DevBuf<uint4> d_jhash;                       // kernels.h: CountTables::jhash
     DevBuf<unsigned long long> d_chunk_origin;   // kernels.h: CountTables::chunk_origin (sized to the largest batch so far)
+    DevBuf<dev::CountTables> d_ctab;             // the count kernel's table block (kernels.h: launch_count) ...
+    dev::CountTables ctab_shadow;                // ... and what it holds
     uint32_t jh_mask = 0;
     DevBuf<uint64_t> d_junc_a, d_junc_b;          // novel-junction records: packed keys (+ sort buffer)
     DevBuf<uint32_t> d_juncw_a, d_juncw_b;        // ... their weights; d_juncw_a.cap follows d_junc_a.cap
@@ -447,14 +449,15 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             gs.push_back(base + ref.roi_start[i]); ge.push_back(base + ref.roi_end[i]); fi.push_back(i);
         }
         n_roi_dev = (uint32_t)fi.size();
+        if (fi.size() >= 0x0fffffffull) return fail(IRF_E_RANGE, "too many ROIs");
         // per bucket: the first ROI that ends at or after the bucket's start, with its extent inline (kernels.h: roi_bkt)
         const uint64_t nb = (full_size >> dev::kBucketShift) + 2;
         std::vector<uint4> bucket(nb);
         size_t p = 0;
         for (uint64_t b = 0; b < nb; b++) {
             while (p < ge.size() && ge[p] < (b << dev::kBucketShift)) p++;
-            if (p < ge.size()) bucket[b] = make_uint4((uint32_t)p, (uint32_t)gs[p], (uint32_t)ge[p], (uint32_t)((gs[p] >> 32) & 0xffffu) | (uint32_t)((ge[p] >> 32) << 16));
-            else bucket[b] = make_uint4((uint32_t)p, 0u, 0u, 0u);
+            if (p < ge.size()) bucket[b] = make_uint4((uint32_t)gs[p], (uint32_t)ge[p], (uint32_t)p | (uint32_t)((gs[p] >> 32) & 3u) << 28 | (uint32_t)((ge[p] >> 32) & 3u) << 30, fi[p]);
+            else bucket[b] = make_uint4(0u, 0u, 0x0fffffffu, 0u);
         }
         TRY(upload(this, d_roi_gstart, gs));
         TRY(upload(this, d_roi_gend, ge));
@@ -493,7 +496,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the cell tables failed");
             const int32_t lo_add = (int32_t)(P.sp_overhang_left + (P.sp_inclusive ? 0u : 1u));
             const int32_t hi_sub = (int32_t)(P.sp_overhang_right + (P.sp_inclusive ? 0u : 1u));
-            dev::launch_build_cells(d_sp_gpos.p, (uint32_t)n_sp_dev, pmap.empty() ? nullptr : d_pmap.p, n_cells, lo_add, 1 - hi_sub, d_cell_s.p,
+            dev::launch_build_cells(d_sp_gpos.p, d_sp_row.p, (uint32_t)n_sp_dev, pmap.empty() ? nullptr : d_pmap.p, n_cells, lo_add, 1 - hi_sub, d_cell_s.p,
                                     d_cell_e.p, stream);
             HIP_TRY(hipGetLastError());
         }
@@ -708,6 +711,8 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         if (e == hipSuccess) e = d_juncw_a.reserve(d_junc_a.cap);
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the junction event buffer failed");
     }
+    if (d_ctab.reserve(1) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the table block failed");
+    memset(&ctab_shadow, 0xff, sizeof ctab_shadow);          // (nothing uploaded yet)
     have_map = true;
     return zero_counters();
 }
@@ -755,7 +760,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.dirty = d_dirty.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_bkt = d_roi_bkt.p; T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
-    T.sp_row = d_sp_row.p; T.sp_cnt = d_sp_cnt.p;
+    T.sp_cnt = d_sp_cnt.p;
     T.known_keys = d_known_keys.p; T.known_kjidx = d_known_kjidx.p; T.n_known = n_known_dev; T.n_kj = n_kj; T.known_cnt = d_known_cnt.p;
     T.known_dir = d_known_dir.p; T.dir_votes = d_scalars.p + 3;
     T.junc_keys = d_junc_a.p; T.junc_w = d_juncw_a.p; T.junc_count = d_scalars.p; T.err_flags = d_err.p;
@@ -862,7 +867,7 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
     if (input_order == IRF_ORDER_ANY && B.n_frag > 1024u) TRY(reorder(B));       // (a batch of a few chunks has nothing to gain)
     {
         // (grown on the stream's own time line: a kernel of an earlier batch may still read the old array)
-        const size_t need = (size_t)B.n_frag / 256 + 1;
+        const size_t need = (size_t)B.n_frag / dev::count_chunk_fragments() + 1;
         if (need > d_chunk_origin.cap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (d_chunk_origin.reserve(need + need / 4) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the chunk table failed");
@@ -876,7 +881,7 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
     }
     auto& evp = count_events[count_events_used++];
     HIP_TRY(hipEventRecord(evp.first, stream));
-    dev::launch_count(count_tables(), B, stream);
+    dev::launch_count(count_tables(), d_ctab.p, &ctab_shadow, B, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(evp.second, stream));
     if (st) HIP_TRY(hipEventRecord(st->consumed, stream));

@@ -47,7 +47,8 @@ enum ErrBits : uint32_t {
 // overhang, so that the cell of bs answers for bs + sp_lo_add and the cell of be for be - sp_hi_sub + 1:
 //   x = points in front of the cell's first (shifted) position, y = bit i: a point at shifted position i of the cell,
 //   z = (plane coordinate of the cell's first position >> 5) | kept << 31 — a cell of a bucket that is not kept maps, whole,
-//       to the start of the next kept bucket (plane_coord above) —, w = 0.
+//       to the start of the next kept bucket (plane_coord above) —, w = the row in sp_cnt of point x (the points of one
+//       chromosome have consecutive rows, so point x + t of the same block has row w + t).
 constexpr int kCellShift = 5;
 __host__ __device__ inline uint32_t junction_hash(uint32_t key_lo, uint32_t key_hi) {
     uint32_t x = key_lo * 0x9E3779B1u + key_hi * 0x85EBCA77u;
@@ -75,14 +76,14 @@ struct CountTables {
     // junction_hash(key): x, y = key (global_left << 28 | span; all ones = empty), z = row of the known-junction table
     const uint4* jhash;
     // FragmentsInROI: per 512-position bucket the first ROI (by end) that ends at or after the bucket's start:
-    // x = its index, y / z = low words of its start / end (full coordinates), w = their high halves (start | end << 16)
+    // x / y = low words of its start / end (full coordinates, < 2^34), z = its index among the sorted ROIs (< 2^28) |
+    // bits 32, 33 of the start << 28 | of the end << 30, w = its index in ref-ROI.bed (the row of roi_cnt)
     const uint4* roi_bkt;
     const uint64_t* roi_gstart;   // ROIs of owned chromosomes sorted by end, in full coordinates (the walk behind roi_bkt)
     const uint64_t* roi_gend;
     const uint32_t* roi_idx;      // file index of the sorted ROI
     uint32_t* roi_cnt;            // [2][n_roi]
     uint32_t* chr_cnt;            // [n_chr][2]
-    const uint32_t* sp_row;       // [points on owned chromosomes] row in sp_cnt
     uint32_t* sp_cnt;             // [2][n_sp]
     uint32_t* known_cnt;          // [2][n_kj]
     int32_t* diff;                // [2][plane_stride]  +1 at block start, -1 at block end
@@ -95,7 +96,7 @@ struct CountTables {
     uint32_t* junc_w;             // ... and their weights (a chunk's events on one junction are merged in LDS first)
     unsigned long long* junc_count;
     uint32_t* err_flags;
-    // [fragments of the batch / 256, rounded up] where the count kernel puts the window of every chunk of 256 fragments
+    // [fragments of the batch / count_chunk_fragments(), rounded up] where the count kernel puts the window of every chunk
     // (written by a kernel of launch_count in front of the count kernel)
     unsigned long long* chunk_origin;
     // known_junction_depth_kernel only: the plane map, the sorted keys (global_left << 28 | span), their rows and strands
@@ -109,8 +110,9 @@ struct CountTables {
 
 // cell tables (device-built at irf_chr_map_update): points = sorted full coordinates of the SpansPoint points on owned
 // chromosomes; shift_s = sp_lo_add, shift_e = 1 - sp_hi_sub (see above)
-void launch_build_cells(const uint64_t* points, uint32_t n_points, const uint32_t* pmap, uint64_t n_cells, int32_t shift_s, int32_t shift_e,
-                        uint4* cell_s, uint4* cell_e, hipStream_t s);
+// (rows[j] = row in sp_cnt of points[j])
+void launch_build_cells(const uint64_t* points, const uint32_t* rows, uint32_t n_points, const uint32_t* pmap, uint64_t n_cells, int32_t shift_s,
+                        int32_t shift_e, uint4* cell_s, uint4* cell_e, hipStream_t s);
 
 struct BatchDev {
     uint32_t n_frag, n_blk;
@@ -124,7 +126,11 @@ struct BatchDev {
     const uint8_t* blk_read;
 };
 
-void launch_count(const CountTables& T, const BatchDev& B, hipStream_t s);
+// The count kernel reads its tables through a pointer (the block is ~50 dwords: as a by-value argument it filled the scalar
+// registers): d_T is a device copy of T that launch_count refreshes (a one-thread kernel on the stream) whenever T differs
+// from *shadow, the host's record of what d_T holds.
+void launch_count(const CountTables& T, CountTables* d_T, CountTables* shadow, const BatchDev& B, hipStream_t s);
+uint32_t count_chunk_fragments();      // fragments per entry of CountTables::chunk_origin
 // difference events of the reads on known junctions, from the junction counters: after the sample's last count kernel,
 // before the carry scan (once per sample)
 void launch_known_junction_depth(const CountTables& T, hipStream_t s);
