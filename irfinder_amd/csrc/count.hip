@@ -17,27 +17,29 @@
 // All outputs are commutative integer sums, so any batch order gives identical
 // results.  Integer work bound by memory latency and by the vector-memory instruction rate: no MFMA.
 //
-// Shape of the kernel (round 3).  The input is CSR (fragments -> blocks).  A workgroup is kWorkers WORKER waves and one
-// FLUSHER wave.  It takes SLICES of the (coordinate-sorted) batch, kSlice chunks of kWorkers x 64 consecutive fragments
-// each, and keeps its LDS accumulators across the chunks of a slice.  Per chunk, between two workgroup barriers each:
-//   F. fragment phase (workers), one fragment per lane: the chromosome record, FragmentsInChr, FragmentsInROI; the
-//      fragment's facts (coordinate base, strand, chromosome length) go to LDS and the lane writes its id over the OWNER
-//      entries of its blocks (with a first / last flag).  MEANWHILE the flusher wave sends what the previous chunks left in
-//      LDS to the tables: the part of the difference window the new chunk has scrolled past, the overflow queue, and every
-//      few chunks the caches (far lines, junction / point / ROI counters, novel junctions).
-//   B. block phase (workers), one block per lane in strides of 63 (lane 63 only looks ahead): one LDS read gives the owner,
-//      one its facts — no search.  Every table question about a position is one 16-byte cell record: the cell of the block
-//      start and the cell of the block end give both plane coordinates and both SpansPoint ranks; the junction to the right
-//      of the block is one probe of the hash table.  Three table loads per block, all independent of each other.  The
-//      successor block's columns, validity and start cell come from the next lane by DPP.  A block owns the junction to its
-//      right and the two difference events next to it (its own end, its successor's start): a read on a known junction
-//      costs one LDS increment of that junction's counter, which also stands for both events (known_junction_depth_kernel
-//      applies them once per junction at finalize).
-// Why a flusher wave: gfx9 retires a wave's vector-memory operations in order under one counter, and a memory-side atomic
-// takes microseconds to be acknowledged, so a wave that has issued ONE global atomic waits that long for its next load.
-// Measured on configs[1]: the 1.1 M ROI atomics alone cost 0.3 of 2.95 ms.  Worker waves therefore issue no global atomic
-// and no global store at all: what does not fit an LDS accumulator goes to an LDS queue (only when that is full, too, does
-// a worker touch the tables itself), and the one wave that issues atomics never waits for a load.
+// Shape of the kernel (round 3).  The input is CSR (fragments -> blocks).  A workgroup takes SLICES of the (coordinate-sorted)
+// batch, kSlice chunks of kFPL x kThreads consecutive fragments each, and keeps its LDS accumulators across the chunks of a
+// slice.  Per chunk, between two workgroup barriers each:
+//   F. fragment phase, kFPL fragments per lane: the chromosome record (a copy of the table in LDS), FragmentsInChr,
+//      FragmentsInROI; the fragment's facts (coordinate base, strand, chromosome length) go to LDS and the lane writes its
+//      id over the OWNER entries of its blocks (with a first / last flag).  Then, with every load of the phase landed, the
+//      waves share the FLUSH of what the previous chunks left in LDS: the part of the difference window the new chunk has
+//      scrolled past, the overflow queue, and every few chunks the caches (far lines, junction / point / ROI counters,
+//      novel junctions).
+//   B. block phase, one block per lane in strides of 63 (lane 63 only looks ahead): one LDS read gives the owner, one its
+//      facts — no search.  Every table question about a position is one 16-byte cell record: the cell of the block start
+//      and the cell of the block end give both plane coordinates and both SpansPoint ranks; the junction to the right of
+//      the block is one probe of the hash table.  Three table loads per block, all independent of each other; the block
+//      columns of a pass are requested one pass ahead.  The successor block's columns, validity and start cell come from
+//      the next lane by DPP.  A block owns the junction to its right and the two difference events next to it (its own
+//      end, its successor's start): a read on a known junction costs one LDS increment of that junction's counter, which
+//      also stands for both events (known_junction_depth_kernel applies them once per junction at finalize).
+// Global atomics are issued in the flush only.  gfx9 retires a wave's vector-memory operations in order under one counter,
+// and a memory-side atomic takes microseconds to be acknowledged, so a wave that has issued ONE global atomic waits that
+// long for its next load (measured on configs[1]: the 1.1 M ROI atomics of an earlier version cost 0.3 of 2.95 ms).  In
+// the phases that wait for loads nothing goes to the tables: what does not fit an LDS accumulator goes to an LDS queue
+// (only when that is full, too, does a lane touch the tables itself); the flush comes when the fragment phase's loads
+// have landed and is followed by a barrier, and chunks are large, so that the one wait behind it is paid once per ~3000 blocks.
 // The difference window is circular (cell = plane position mod kWin) and SCROLLS with the chunks: what a chunk's first
 // fragment leaves behind is flushed (one global atomic per non-zero cell, whole 64-byte lines), the rest stays and keeps
 // merging events of later chunks.
@@ -52,8 +54,8 @@ namespace dev {
 namespace {
 
 #ifdef COUNT_PROF
-// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of worker wave 0, the last worker
-// wave and the flusher wave per phase and workgroup
+// diagnostic build only (tools/build_variant.sh -DCOUNT_PROF): wall-clock ticks (10 ns) of the first and the last wave per
+// phase and workgroup
 __device__ uint32_t g_cprof[2048][3][8];
 #define CPROF(k) do { if (lane == 0u && prof_on) { const unsigned long long now_ = wall_clock64(); prof_acc[k] += (uint32_t)(now_ - prof_t); prof_t = now_; } } while (0)
 // ... and what the flusher did, summed over the launch: 0 window steps looked at, 1 of them not empty, 2 line steps not empty,
@@ -65,22 +67,17 @@ __device__ unsigned long long g_cstat[8];
 #define CSTAT(k, n) do { } while (0)
 #endif
 
-#ifndef K_WORKERS
-#define K_WORKERS 6
+#ifndef K_WAVES
+#define K_WAVES 8
 #endif
-#ifndef K_FLUSHERS
-#define K_FLUSHERS 2
-#endif
-#if K_WORKERS > 4
-#define K_BIG 1
-#else
-#define K_BIG 0
+#ifndef K_FPL
+#define K_FPL 1
 #endif
 #ifndef K_WIN
-#define K_WIN (K_BIG ? 4096 : 2048)
+#define K_WIN 2048
 #endif
 #ifndef K_LINES
-#define K_LINES (K_BIG ? 256 : 128)
+#define K_LINES 128
 #endif
 #ifndef K_JCACHE
 #define K_JCACHE 256
@@ -89,26 +86,25 @@ __device__ unsigned long long g_cstat[8];
 #define K_PCACHE 128
 #endif
 #ifndef K_TILE
-#define K_TILE (K_BIG ? 2048 : 1024)
+#define K_TILE 4096
 #endif
 #ifndef K_SLICE
-#define K_SLICE (K_BIG ? 8 : 16)
+#define K_SLICE 8
 #endif
 #ifndef K_FLUSH
-#define K_FLUSH (K_BIG ? 2 : 4)
+#define K_FLUSH 2
 #endif
 #ifndef K_WGS_PER_CU
-#define K_WGS_PER_CU (K_BIG ? 3 : 5)
+#define K_WGS_PER_CU 3
 #endif
 #ifndef K_BU
 #define K_BU 1
 #endif
-constexpr uint32_t kWorkers = K_WORKERS;            // worker waves per workgroup; the waves behind them are the flushers:
-constexpr uint32_t kFlushers = K_FLUSHERS;          // one (window, queue, caches) or two (window + queue | caches)
-static_assert(kFlushers == 1u || kFlushers == 2u, "K_FLUSHERS");
-constexpr int kThreads = (K_WORKERS + K_FLUSHERS) * 64;
-constexpr int kWavesPerSimd = (K_WGS_PER_CU * (K_WORKERS + K_FLUSHERS) + 3) / 4;
-constexpr uint32_t kChunk = kWorkers * 64u;         // fragments per chunk: one per worker lane
+constexpr uint32_t kWaves = K_WAVES;
+constexpr int kThreads = K_WAVES * 64;
+constexpr int kWavesPerSimd = (K_WGS_PER_CU * K_WAVES + 3) / 4;
+constexpr int kFPL = K_FPL;                         // fragments per lane and chunk
+constexpr uint32_t kChunk = kFPL * kThreads;        // fragments per chunk
 constexpr uint32_t kTile = K_TILE;                  // owner entries: blocks of a chunk are processed in tiles of this many
 constexpr uint32_t kSlice = K_SLICE;                // chunks per slice (a workgroup's unit of work; accumulators live this long)
 constexpr uint32_t kFlushEvery = K_FLUSH;           // chunks between two flushes of the caches
@@ -124,7 +120,7 @@ constexpr uint32_t kPCache = K_PCACHE;              // LDS cache of SpansPoint c
 constexpr uint32_t kRCache = 64;                    // LDS cache of ROI counters (direct-mapped on the ROI's row)
 constexpr uint32_t kNovelQ = 64;                    // LDS queue of novel-junction events (those the table below has no room for)
 constexpr uint32_t kNovelH = 128;                   // LDS table that merges novel-junction events by key (open addressing, 4 probes)
-constexpr uint32_t kOQ = 256;                       // LDS queue of updates that found their cache slot taken (drained every chunk)
+constexpr uint32_t kOQ = 128;                       // LDS queues (two, taking turns) of updates that found their cache slot taken
 constexpr unsigned long long kEmpty64 = ~0ull;      // (no event has bit 63 set)
 // The window and the line cache keep both strands of a position as 16-bit halves of one word.  A chunk with more blocks than
 // kWinMaxBlocks bypasses them; everything is flushed before the events added since the last complete flush can exceed 2^15.
@@ -132,10 +128,9 @@ constexpr uint32_t kWinMaxBlocks = 4000;
 constexpr uint32_t kEvFlush = 22000;                // + 2 * kWinMaxBlocks < 32768
 constexpr unsigned long long kNoWin = ~0ull;
 constexpr uint32_t kFragValid = 1u << 31, kFragDir = 1u << 30, kFragBaseMask = (1u << 28) - 1u;   // base >> 6 (base is a multiple of 64, < 2^34)
-constexpr uint32_t kOwnFirst = 0x4000u, kOwnLast = 0x8000u, kOwnMask = 0x1ffu;
-static_assert(kChunk <= 512u, "owner ids are 9 bits");
+constexpr uint32_t kOwnFirst = 0x4000u, kOwnLast = 0x8000u, kOwnMask = 0x3fffu;
+static_assert(kChunk <= 0x4000u, "owner ids are 14 bits");
 static_assert(kWin % 64u == 0u && (kWin & (kWin - 1u)) == 0u, "K_WIN");
-static_assert((kLines * 16u) % 64u == 0u, "the line flush runs with whole waves (DPP sums)");
 static_assert(kEvFlush + 2u * kWinMaxBlocks < 32768u && 2u * kFlushEvery * kWinMaxBlocks <= 32768u, "packed 16-bit halves");
 
 // entries of the overflow queue: kind << 62 | strand << 61 | ...
@@ -165,14 +160,14 @@ struct Lds {
     unsigned long long nq[kNovelQ];
     unsigned long long nh_key[kNovelH];
     uint32_t nh_cnt[kNovelH];
-    unsigned long long oq[kOQ];
+    unsigned long long oq[2][kOQ];
     uint32_t chr[kChrBins];
     u32x4 chrtab[kChrTab];             // chr_rec of the first kChrTab references (the fragment phase then waits for no load)
     // the claimed slots of the four caches, in the order they were claimed (the flusher walks these, not the caches)
     uint16_t llist[kLines], jlist[kJCache], plist[kPCache], rlist[kRCache];
     uint32_t ll_n, jl_n, pl_n, rl_n;
     uint32_t wmax[2];                  // highest window offset + 1 a chunk touched
-    uint32_t nq_n, nh_n, oq_n;
+    uint32_t nq_n, nh_n, oq_n[2], oq_cur;   // oq_cur: the queue the block phase fills (the flush drains the other one)
 };
 
 // Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
@@ -261,8 +256,9 @@ __device__ __forceinline__ void oq_apply(const CountTables& T, unsigned long lon
 
 // ---- worker side: LDS accumulators, and the queue when a slot is taken --------------------------------------------
 __device__ __forceinline__ void oq_push(const CountTables& T, Lds& S, unsigned long long e) {
-    const uint32_t q = atomicAdd(&S.oq_n, 1u);
-    if (q < kOQ) S.oq[q] = e;
+    const uint32_t b = S.oq_cur;
+    const uint32_t q = atomicAdd(&S.oq_n[b], 1u);
+    if (q < kOQ) S.oq[b][q] = e;
     else oq_apply(T, e);            // (queue full: the worker pays for the atomic itself)
 }
 
@@ -354,70 +350,65 @@ __device__ __forceinline__ void novel_add(const CountTables& T, Lds& S, unsigned
     }
 }
 
-// ---- flusher side (one wave) ----------------------------------------------------------------------------------
+// ---- the flush: LDS accumulators -> the tables, shared by the waves of the workgroup ------------------------------
 // Window cells of the positions win + [0, to): one global atomic per non-zero cell and strand, consecutive lanes =
-// consecutive positions (whole 64-byte lines for the memory-side atomic unit); the cells are left zero.
-__device__ __forceinline__ void flush_window(const CountTables& T, Lds& S, unsigned long long win, uint32_t to, uint32_t lane, uint32_t* s_cstat_local) {
-    // (segment sums and line marks leave once per 256-position segment: the steps of a segment add up first)
-    int32_t acc = 0;                    // packed sums of the current segment (lane 63)
-    uint32_t marks = 0;                 // bit k: step k of the current segment held something
-    auto close_segment = [&](uint64_t seg_pos) {          // seg_pos: the segment's first position
-        const int32_t tot = __builtin_amdgcn_readlane(acc, 63);
-        const int32_t t0 = (int32_t)(int16_t)(uint16_t)(tot & 0xffff), t1 = (tot - t0) >> 16;
-        if (lane >= 62u) {              // lane 63 adds strand 0's sum, lane 62 strand 1's: one instruction
-            const uint32_t dir = 63u - lane;
-            const int32_t v = dir ? t1 : t0;
-            if (v) seg_add(T, dir, seg_pos, v);
-        }
-        // the marks of the segment's 16 lines, both strands: 8 bytes per step that held something
-        if (lane < 4u && ((marks >> lane) & 1u))
-#ifndef K_DIAG_NO_ATOMICS
-            *reinterpret_cast<AS1 unsigned long long*>(gp(T.dirty) + ((((seg_pos >> 8) << 2) + lane) << 3)) = 0x0101010101010101ull;
-#else
-            (void)0;
-#endif
-        acc = 0; marks = 0;
-    };
-    uint64_t cur_seg = ~0ull;
-    for (uint32_t g4 = 0; g4 < to; g4 += 256u) {
-    int32_t v4[4];
+// consecutive positions (whole 64-byte lines for the memory-side atomic unit); the cells are left zero.  A wave takes whole
+// 256-position segments, so that the segment's sum and the marks of its lines leave once.
+__device__ __forceinline__ void flush_window(const CountTables& T, Lds& S, unsigned long long win, uint32_t to, uint32_t lane, uint32_t wave, uint32_t* s_cstat_local) {
+    if (!to) return;
+    const uint64_t seg_last = (win + to - 1u) >> 8;
+    for (uint64_t seg = (win >> 8) + ((wave + kWaves - (uint32_t)((win >> 8) % kWaves)) % kWaves); seg <= seg_last; seg += kWaves) {
+        int32_t v4[4];
+        bool in4[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v4[k] = S.tile[(uint32_t)(win + g4 + 64u * k + lane) & (kWin - 1u)];     // (cells behind `to` are the window's own, too)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t g = g4 + 64u * k;
-        if (g >= to) continue;
-        CSTAT(0, 1u);
-        const uint64_t p = win + g + lane;                              // (win and g are multiples of 64: one segment per step)
-        const uint32_t idx = (uint32_t)p & (kWin - 1u);
-        const int32_t v = v4[k];
-        if (__ballot(v != 0) == 0ull) continue;                         // (nothing in these 64 positions)
-        CSTAT(1, 1u);
-        const uint64_t seg = (win + g) >> 8;
-        if (seg != cur_seg) { if (cur_seg != ~0ull) close_segment(cur_seg << 8); cur_seg = seg; }
-        const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
-        const int32_t v1 = (v - v0) >> 16;
-        if (v) {
-            AS1 int32_t* d = gp(T.diff) + p;
-#ifndef K_DIAG_NO_ATOMICS
-            if (v0) __hip_atomic_fetch_add(d, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v1) __hip_atomic_fetch_add(d + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-            S.tile[idx] = 0;
+        for (int k = 0; k < 4; k++) {
+            const uint64_t p0 = (seg << 8) + 64u * k;
+            in4[k] = p0 >= win && p0 < win + to;
+            v4[k] = in4[k] ? S.tile[(uint32_t)(p0 + lane) & (kWin - 1u)] : 0;
         }
-        // (the two strands' sums in one pass: the packed halves of a sum cannot overflow, see kEvFlush)
-        acc += wave_sum_dpp(v);
-        marks |= 1u << (uint32_t)(((win + g) >> 6) & 3u);
+        int32_t acc = 0;                    // packed sums of the segment (lane 63)
+        uint32_t marks = 0;                 // bit k: step k of the segment held something
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            CSTAT(0, in4[k] ? 1u : 0u);
+            const int32_t v = v4[k];
+            if (__ballot(v != 0) == 0ull) continue;                     // (nothing in these 64 positions)
+            CSTAT(1, 1u);
+            const uint64_t p = (seg << 8) + 64u * k + lane;
+            const int32_t v0 = (int32_t)(int16_t)(uint16_t)(v & 0xffff);
+            const int32_t v1 = (v - v0) >> 16;
+            if (v) {
+#ifndef K_DIAG_NO_ATOMICS
+                AS1 int32_t* d = gp(T.diff) + p;
+                if (v0) __hip_atomic_fetch_add(d, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v1) __hip_atomic_fetch_add(d + T.plane_stride, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                S.tile[(uint32_t)p & (kWin - 1u)] = 0;
+            }
+            // (the two strands' sums in one pass: the packed halves of a sum cannot overflow, see kEvFlush)
+            acc += wave_sum_dpp(v);
+            marks |= 1u << k;
+        }
+        if (marks) {
+            const int32_t tot = __builtin_amdgcn_readlane(acc, 63);
+            const int32_t t0 = (int32_t)(int16_t)(uint16_t)(tot & 0xffff), t1 = (tot - t0) >> 16;
+            if (lane >= 62u) {              // lane 63 adds strand 0's sum, lane 62 strand 1's: one instruction
+                const uint32_t dir = 63u - lane;
+                const int32_t v = dir ? t1 : t0;
+                if (v) seg_add(T, dir, seg << 8, v);
+            }
+#ifndef K_DIAG_NO_ATOMICS
+            // the marks of the segment's 16 lines, both strands: 8 bytes per step that held something
+            if (lane < 4u && ((marks >> lane) & 1u)) *reinterpret_cast<AS1 unsigned long long*>(gp(T.dirty) + (((seg << 2) + lane) << 3)) = 0x0101010101010101ull;
+#endif
+        }
     }
-    }
-    if (cur_seg != ~0ull) close_segment(cur_seg << 8);
 }
 
-// counters of a direct-mapped cache -> a [2][n_rows] table
+// counters of a direct-mapped cache -> a [2][n_rows] table (n: the claimed slots; the caller resets the count)
 template <uint32_t N>
-__device__ __forceinline__ void flush_cache(uint32_t* tags, uint32_t (*cnt)[N], uint16_t* list, uint32_t* list_n, uint32_t* table, uint64_t n_rows, uint32_t lane) {
-    const uint32_t n = *list_n;
-    for (uint32_t i = lane; i < n; i += 64u) {
+__device__ __forceinline__ void flush_cache(uint32_t* tags, uint32_t (*cnt)[N], const uint16_t* list, uint32_t n, uint32_t* table, uint64_t n_rows, uint32_t tid) {
+    for (uint32_t i = tid; i < n; i += kThreads) {
         const uint32_t e = list[i];
         const uint32_t row = tags[e];
         const uint32_t c0 = cnt[0][e], c1 = cnt[1][e];
@@ -425,22 +416,11 @@ __device__ __forceinline__ void flush_cache(uint32_t* tags, uint32_t (*cnt)[N], 
         if (c1) add_u32(table + n_rows + row, c1);
         tags[e] = kEmpty; cnt[0][e] = 0; cnt[1][e] = 0;
     }
-    if (lane == 0u && n) *list_n = 0;
 }
 
-__device__ __forceinline__ void flush_queue(const CountTables& T, Lds& S, uint32_t lane) {
-    const uint32_t n = S.oq_n < kOQ ? S.oq_n : kOQ;
-    for (uint32_t e = lane; e < n; e += 64u) oq_apply(T, S.oq[e]);
-    if (lane == 0u && n) S.oq_n = 0;
-}
-
-// Far-line cache, junction / point / ROI counters, novel junctions -> the tables; all left empty.
-// (qb: the slice of the record buffer reserved for the nh + nq novel-junction records, in lane 0 — reserved by the caller
-//  before its other atomics, so that the wait for the returned value is one round trip)
-__device__ __forceinline__ void flush_caches(const CountTables& T, Lds& S, uint32_t lane, uint32_t& err, unsigned long long qb, uint32_t nq, uint32_t nh,
-                                             uint32_t* s_cstat_local) {
-    const uint32_t n_lines = S.ll_n;
-    for (uint32_t e0 = 0; e0 < n_lines; e0 += 4u) {                 // the claimed lines, four per step
+// the claimed lines of the far-event cache, four per wave and step
+__device__ __forceinline__ void flush_lines(const CountTables& T, Lds& S, uint32_t n_lines, uint32_t lane, uint32_t wave, uint32_t* s_cstat_local) {
+    for (uint32_t e0 = wave * 4u; e0 < n_lines; e0 += kWaves * 4u) {
         const uint32_t li = e0 + (lane >> 4), cell = lane & 15u;    // a 16-lane row = one line = inside one segment
         const uint32_t slot = li < n_lines ? S.llist[li] : kLines;
         const uint32_t tag = li < n_lines ? S.ltag[slot] : kEmpty;
@@ -474,33 +454,32 @@ __device__ __forceinline__ void flush_caches(const CountTables& T, Lds& S, uint3
             S.ltag[slot] = kEmpty;          // (the row's 16 lanes have read the tag: same wave, program order)
         }
     }
-    if (lane == 0u && n_lines) S.ll_n = 0;
-    flush_cache<kJCache>(S.jtag, S.jcnt, S.jlist, &S.jl_n, T.known_cnt, T.n_kj, lane);
-    flush_cache<kPCache>(S.ptag, S.pcnt, S.plist, &S.pl_n, T.sp_cnt, T.n_sp, lane);
-    flush_cache<kRCache>(S.rtag, S.rcnt, S.rlist, &S.rl_n, T.roi_cnt, T.n_roi, lane);
-    {
-        // novel-junction records: the merged table first (compacted with ballots), then the queue (weight 1)
-        if (nq + nh) {
-            qb = __shfl(qb, 0);
-            uint32_t at = 0;
+}
+
+// novel-junction records (one wave): the merged table first (compacted with ballots), then the queue (weight 1)
+__device__ __forceinline__ void flush_novel(const CountTables& T, Lds& S, uint32_t lane, uint32_t& err) {
+    const uint32_t nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ, nh = S.nh_n;
+    if (!(nq + nh)) return;
+    unsigned long long qb = 0;
+    if (lane == 0u) qb = __hip_atomic_fetch_add(gp(T.junc_count), (unsigned long long)(nq + nh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    qb = __shfl(qb, 0);
+    uint32_t at = 0;
 #pragma unroll
-            for (uint32_t e0 = 0; e0 < kNovelH; e0 += 64u) {
-                const unsigned long long k = S.nh_key[e0 + lane];
-                const uint32_t w = S.nh_cnt[e0 + lane];
-                const uint64_t occ = __ballot(k != kEmpty64);
-                if (k != kEmpty64) {
-                    const unsigned long long slot = qb + at + (unsigned long long)__popcll(occ & ((1ull << lane) - 1ull));
-                    if (slot < T.junc_capacity) { gp(T.junc_keys)[slot] = k; gp(T.junc_w)[slot] = w; } else err |= ERR_JUNC_CAPACITY;
-                    S.nh_key[e0 + lane] = kEmpty64; S.nh_cnt[e0 + lane] = 0;
-                }
-                at += (uint32_t)__popcll(occ);
-            }
-            for (uint32_t e = lane; e < nq; e += 64u) {
-                if (qb + nh + e < T.junc_capacity) { gp(T.junc_keys)[qb + nh + e] = S.nq[e]; gp(T.junc_w)[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
-            }
-            if (lane == 0u) { S.nq_n = 0; S.nh_n = 0; }
+    for (uint32_t e0 = 0; e0 < kNovelH; e0 += 64u) {
+        const unsigned long long k = S.nh_key[e0 + lane];
+        const uint32_t w = S.nh_cnt[e0 + lane];
+        const uint64_t occ = __ballot(k != kEmpty64);
+        if (k != kEmpty64) {
+            const unsigned long long slot = qb + at + (unsigned long long)__popcll(occ & ((1ull << lane) - 1ull));
+            if (slot < T.junc_capacity) { gp(T.junc_keys)[slot] = k; gp(T.junc_w)[slot] = w; } else err |= ERR_JUNC_CAPACITY;
+            S.nh_key[e0 + lane] = kEmpty64; S.nh_cnt[e0 + lane] = 0;
         }
+        at += (uint32_t)__popcll(occ);
     }
+    for (uint32_t e = lane; e < nq; e += 64u) {
+        if (qb + nh + e < T.junc_capacity) { gp(T.junc_keys)[qb + nh + e] = S.nq[e]; gp(T.junc_w)[qb + nh + e] = 1u; } else err |= ERR_JUNC_CAPACITY;
+    }
+    if (lane == 0u) { S.nq_n = 0; S.nh_n = 0; }
 }
 
 // Where every chunk puts its window: the plane position, rounded down to 64, of the start of its first fragment; kNoWin: that
@@ -539,170 +518,137 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
     for (uint32_t k = tid; k < kPCache; k += kThreads) { S.ptag[k] = kEmpty; S.pcnt[0][k] = 0; S.pcnt[1][k] = 0; }
     for (uint32_t k = tid; k < kRCache; k += kThreads) { S.rtag[k] = kEmpty; S.rcnt[0][k] = 0; S.rcnt[1][k] = 0; }
     for (uint32_t k = tid; k < kNovelH; k += kThreads) { S.nh_key[k] = kEmpty64; S.nh_cnt[k] = 0; }
-    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.oq_n = 0; S.wmax[0] = 0; S.wmax[1] = 0; S.ll_n = 0; S.jl_n = 0; S.pl_n = 0; S.rl_n = 0; }
+    if (tid == 0) { S.nq_n = 0; S.nh_n = 0; S.oq_n[0] = 0; S.oq_n[1] = 0; S.oq_cur = 0; S.wmax[0] = 0; S.wmax[1] = 0; S.ll_n = 0; S.jl_n = 0; S.pl_n = 0; S.rl_n = 0; }
     for (uint32_t k = tid; k < kChrTab; k += kThreads) S.chrtab[k] = k < T.n_chr ? ((const AS1 u32x4*)T.chr_rec)[k] : u32x4{0u, 0u, 0u, 0u};
 
     uint32_t err = 0;
+    uint32_t s_cstat_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (used by the diagnostic build only)
 #ifdef COUNT_PROF
-    const bool prof_on = wave == 0u || wave == kWorkers - 1u || wave == kWorkers;
+    const bool prof_on = wave == 0u || wave == kWaves - 1u;
     unsigned long long prof_t = wall_clock64();
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
     const uint32_t n_slices = (n_chunks + kSlice - 1u) / kSlice;
     const AS1 unsigned long long* origin = gp((const unsigned long long*)T.chunk_origin);
-    // block range of a chunk (clamped: the offsets of a device-resident batch are not trusted)
-    auto chunk_blocks = [&](uint32_t c, uint32_t& kb0, uint32_t& kb1) {
-        const uint32_t f0 = c * kChunk;
-        const uint32_t f_end = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
-        kb0 = B.frag_blk_off[f0]; kb1 = B.frag_blk_off[f_end];
-        kb0 = kb0 < B.n_blk ? kb0 : B.n_blk;
-        kb1 = kb1 < B.n_blk ? kb1 : B.n_blk;
-        if (kb1 < kb0) kb1 = kb0;
+    const AS1 u32x4* cell_s = (const AS1 u32x4*)T.cell_s;
+    const AS1 u32x4* cell_e = (const AS1 u32x4*)T.cell_e;
+    const AS1 u32x4* jhash = (const AS1 u32x4*)T.jhash;
+    const AS1 u32x4* chr_rec = (const AS1 u32x4*)T.chr_rec;
+    const AS1 u32x4* roi_bkt = (const AS1 u32x4*)T.roi_bkt;
+    const uint32_t jh_mask = T.jh_mask, n_chr = T.n_chr, n_roi_dev = T.n_roi_dev, junc_min_flank = T.junc_min_flank, sp_min_len = T.sp_min_len;
+    struct Cols { uint32_t bs, bl, rd; };
+    auto load_cols = [&](uint32_t k) -> Cols {
+        Cols c = {0u, 0u, 0u};
+        if (B.n_blk == 0u) return c;            // (fragments without any block: the arrays may not exist)
+        const uint32_t kc = k < B.n_blk ? k : B.n_blk - 1u;
+        c.bs = B.blk_start[kc]; c.bl = B.blk_len[kc]; c.rd = B.blk_read[kc];
+        return c;
     };
 
-    uint32_t s_cstat_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (used by the diagnostic build only)
-    if (wave >= kWorkers) {
-        // ======================= the flusher waves =======================
-        // (one flusher does everything; of two, the first takes the window and the queue, the second the caches: no word
-        //  of LDS is written by both)
-        const bool do_win = wave == kWorkers, do_cch = wave == kWorkers + kFlushers - 1u;
-        for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
-            const uint32_t c0 = slice * kSlice;
-            const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
-            unsigned long long win = 0;     // window = plane positions [win, win + kWin)
-            uint32_t wtop = 0;              // cells of win + [0, wtop) may be non-zero
-            uint32_t ev_since = 0;          // upper bound of the events added since everything was last flushed
-            uint32_t since_flush = 0;       // chunks since the caches were last flushed
-            for (uint32_t i = 0; i <= nc; i++) {
-                CPROF(3);
-                wg_barrier();               // ---- the block phase of chunk i - 1 is over (i = 0: the LDS is initialised) ----
-                CPROF(0);
-                wtop = umax(wtop, S.wmax[(i + 1u) & 1u]);      // (i = 0: may be the previous slice's; too large does no harm)
-                const bool last = i == nc;
-                const unsigned long long nw = last ? kNoWin : origin[c0 + i];
-                if (lane == 0u && do_win) S.wmax[i & 1u] = 0;
-                const bool ev_full = ev_since > kEvFlush;
-                bool jump = false;
-                uint32_t scroll = 0;
-                if (nw != kNoWin) {
-                    if (nw < win || nw - win >= kWin) jump = true; else scroll = (uint32_t)(nw - win);
-                }
-                since_flush++;
-                const bool do_caches = last || ev_full || since_flush >= kFlushEvery;
-                unsigned long long qb = 0;
-                uint32_t nq = 0, nh = 0;
-                if (do_caches && do_cch) {
-                    nq = S.nq_n < kNovelQ ? S.nq_n : kNovelQ; nh = S.nh_n;
-                    if (lane == 0u && nq + nh) qb = __hip_atomic_fetch_add(gp(T.junc_count), (unsigned long long)(nq + nh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                // the window follows the chunks
-                if (last || ev_full || jump) {
-                    if (do_win) flush_window(T, S, win, wtop, lane, s_cstat_local);
-                    wtop = 0;
-                    CSTAT(4, jump ? 1u : 0u);
-                } else if (scroll) {
-                    if (do_win) flush_window(T, S, win, scroll < wtop ? scroll : wtop, lane, s_cstat_local);
-                    wtop = wtop > scroll ? wtop - scroll : 0u;
-                }
-                if (nw != kNoWin) win = nw;
-                if (do_win) {
-                    CSTAT(3, S.oq_n); CSTAT(6, 1u);
-                    flush_queue(T, S, lane);
-                }
-                if (do_caches) {
-                    if (do_cch) {
-                        CSTAT(5, 1u);
-                        flush_caches(T, S, lane, err, qb, nq, nh, s_cstat_local);
-                    }
-                    since_flush = 0;
-                }
-                if (last || ev_full) ev_since = 0;
-                CPROF(1);
-                if (last) break;            // (the slice's accumulators are empty again)
-                uint32_t kb0, kb1;
-                chunk_blocks(c0 + i, kb0, kb1);
-                if (kb1 - kb0 <= kWinMaxBlocks) ev_since += 2u * (kb1 - kb0);
-                CPROF(2);
-                wg_barrier();               // ---- the workers start the block phase ----
-                for (uint32_t t0 = kb0 + kTile; t0 < kb1; t0 += kTile) { wg_barrier(); wg_barrier(); }     // (their owner tiles)
-            }
-        }
-    } else {
-        // ======================= the worker waves =======================
-        const AS1 u32x4* cell_s = (const AS1 u32x4*)T.cell_s;
-        const AS1 u32x4* cell_e = (const AS1 u32x4*)T.cell_e;
-        const AS1 u32x4* jhash = (const AS1 u32x4*)T.jhash;
-        const AS1 u32x4* chr_rec = (const AS1 u32x4*)T.chr_rec;
-        const AS1 u32x4* roi_bkt = (const AS1 u32x4*)T.roi_bkt;
-        const uint32_t jh_mask = T.jh_mask, n_chr = T.n_chr, n_roi_dev = T.n_roi_dev, junc_min_flank = T.junc_min_flank, sp_min_len = T.sp_min_len;
-        // the columns of a chunk's fragments: loaded one chunk ahead
-        struct Cols { uint32_t bs, bl, rd; };
-        auto load_cols = [&](uint32_t k) -> Cols {
-            Cols c = {0u, 0u, 0u};
-            if (B.n_blk == 0u) return c;            // (fragments without any block: the arrays may not exist)
-            const uint32_t kc = k < B.n_blk ? k : B.n_blk - 1u;
-            c.bs = B.blk_start[kc]; c.bl = B.blk_len[kc]; c.rd = B.blk_read[kc];
-            return c;
-        };
-        struct FragCols { uint32_t chr, fs, fe, o0, o1, flg; };
-        auto load_frag = [&](uint32_t c) -> FragCols {
-            FragCols r;
-            const uint32_t f = c * kChunk + tid;
+    // the columns of a chunk's fragments: requested one chunk ahead, under the block phase
+    struct FragCols { uint32_t chr[kFPL], fs[kFPL], fe[kFPL], o0[kFPL], o1[kFPL], flg[kFPL]; };
+    auto load_frag = [&](uint32_t c) -> FragCols {
+        FragCols r;
+#pragma unroll
+        for (int j = 0; j < kFPL; j++) {
+            const uint32_t f = c * kChunk + j * kThreads + tid;
             const uint32_t fc = f < B.n_frag ? f : B.n_frag - 1u;
-            r.chr = B.frag_chr[fc]; r.fs = B.frag_start[fc]; r.fe = B.frag_end[fc];
-            r.o0 = B.frag_blk_off[fc]; r.o1 = B.frag_blk_off[fc + 1u]; r.flg = B.frag_flags[fc];
-            return r;
-        };
-        for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
-            const uint32_t c0 = slice * kSlice;
-            const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
-            unsigned long long win = 0;
-            FragCols fc_next = load_frag(c0);
-            for (uint32_t i = 0; i <= nc; i++) {
-                CPROF(3);
-                wg_barrier();               // ---- the block phase of chunk i - 1 is over ----
-                CPROF(0);
-                if (i == nc) break;         // (the flusher empties the slice's accumulators)
-                const unsigned long long nw = origin[c0 + i];
-                if (nw != kNoWin) win = nw;
+            r.chr[j] = B.frag_chr[fc]; r.fs[j] = B.frag_start[fc]; r.fe[j] = B.frag_end[fc];
+            r.o0[j] = B.frag_blk_off[fc]; r.o1[j] = B.frag_blk_off[fc + 1u]; r.flg[j] = B.frag_flags[fc];
+        }
+        return r;
+    };
+    for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        const uint32_t c0 = slice * kSlice;
+        const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
+        FragCols fc_next = load_frag(c0);
+        unsigned long long win = 0;     // window = plane positions [win, win + kWin); uniform over the workgroup, like the next three
+        uint32_t wtop = 0;              // cells of win + [0, wtop) may be non-zero
+        uint32_t ev_since = 0;          // upper bound of the events added since everything was last flushed
+        uint32_t since_flush = 0;       // chunks since the caches were last flushed
+        for (uint32_t i = 0; i <= nc; i++) {
+            CPROF(3);
+            wg_barrier();               // ---- the block phase of chunk i - 1 is over (i = 0: the LDS is initialised / flushed) ----
+            CPROF(0);
+            const bool last = i == nc;
+            // what the flush below will work on (read now: the words are reset behind it)
+            wtop = umax(wtop, S.wmax[(i + 1u) & 1u]);      // (i = 0: may be the previous slice's; too large does no harm)
+            // (the queue chunk i - 1 filled; a slice begins with both queues drained, whatever their counts say)
+            const uint32_t n_oq = i == 0u ? 0u : (S.oq_n[(i + 1u) & 1u] < kOQ ? S.oq_n[(i + 1u) & 1u] : kOQ);
+            const unsigned long long win_old = win;
+            const unsigned long long nw = last ? kNoWin : origin[c0 + i];
+            if (tid == 0) { S.wmax[i & 1u] = 0; S.oq_n[i & 1u] = 0; S.oq_cur = i & 1u; }
+            const bool ev_full = ev_since > kEvFlush;
+            bool jump = false;
+            uint32_t scroll = 0;
+            if (nw != kNoWin) {
+                if (nw < win || nw - win >= kWin) jump = true; else scroll = (uint32_t)(nw - win);
+            }
+            uint32_t flush_to = 0;                          // the window cells win_old + [0, flush_to) leave
+            if (last || ev_full || jump) { flush_to = wtop; wtop = 0; }
+            else if (scroll) { flush_to = scroll < wtop ? scroll : wtop; wtop = wtop > scroll ? wtop - scroll : 0u; }
+            if (nw != kNoWin) win = nw;
+            since_flush++;
+            const bool do_caches = last || ev_full || since_flush >= kFlushEvery;
+            if (do_caches) since_flush = 0;
+            if (last || ev_full) ev_since = 0;
 
-                // ---------------- F. fragment phase of chunk i ----------------
-                const uint32_t f = (c0 + i) * kChunk + tid;
-                const bool in = f < B.n_frag;
-                const uint32_t chr = fc_next.chr, fs = fc_next.fs, fe = fc_next.fe, o0 = fc_next.o0, o1 = fc_next.o1, flg = fc_next.flg;
-                uint32_t kb0, kb1;
-                chunk_blocks(c0 + i, kb0, kb1);
-                // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here): inside
-                // the array's bounds, non-decreasing, spanning [0, n_blk].  Clamped, they address nothing out of bounds.
-                if (in && (o0 > B.n_blk || o1 > B.n_blk || o1 < o0 || (f == 0u && o0 != 0u) || (f == B.n_frag - 1u && o1 != B.n_blk))) err |= ERR_CSR;
-                uint32_t o0c = o0 < B.n_blk ? o0 : B.n_blk, o1c = o1 < B.n_blk ? o1 : B.n_blk;
-                if (!in) { o0c = 0; o1c = 0; }
-                const bool chr_ok = in && chr < n_chr;
-                if (in && !chr_ok) err |= ERR_CHR_RANGE;
-                u32x4 rec = S.chrtab[chr_ok && chr < kChrTab ? chr : 0u];
-                if (chr_ok && chr >= kChrTab) rec = chr_rec[chr];
-                const bool counted = chr_ok && rec.w != 0u;
-                const uint64_t base = (uint64_t)rec.y << 32 | rec.x;
-                const uint32_t clen = rec.z;
-                const uint32_t dir = flg & 1u;
-                S.facts[tid] = counted ? make_uint2((uint32_t)(base >> 6) | (dir ? kFragDir : 0u) | kFragValid, clen) : make_uint2(0u, 0u);
-                // the owner entries of the fragment's blocks (first tile; the others below)
-                auto scatter = [&](uint32_t t0) {
-                    for (uint32_t k = o0c > t0 ? o0c : t0; k < o1c && k - t0 <= kTile; k++)
-                        S.owner[k - t0] = (uint16_t)(tid | (k == o0c ? kOwnFirst : 0u) | (k + 1u == o1c ? kOwnLast : 0u));
-                };
-                scatter(kb0);
-                // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment.  The record
-                // is requested here and looked at behind the barrier (the fragment phase waits for no load; and until then
-                // the caches and the queue are the flusher's)
-                const bool extent_ok = n_roi_dev != 0u && counted && fs <= fe && fe <= clen;
-                const uint64_t gfs = base + fs, gfe = base + fe;
-                const u32x4 R = roi_bkt[extent_ok ? gfe >> kBucketShift : 0ull];
-                // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
-                unsigned long long chr_over = 0ull;      // (a reference beyond the LDS histogram: through the queue, behind the barrier)
-                {
-                    const uint32_t k = counted ? chr * 2u + dir : kEmpty;
+            // ---------------- F. fragment phase of chunk i ----------------
+            uint32_t kb0 = 0, kb1 = 0;
+            uint32_t roi_row[kFPL];                   // row of roi_cnt | strand << 31, or kEmpty
+            Cols nxt[kBU];
+            // the owner entries of the blocks [a, b) of the lane's fragment j that lie in tile t0
+            auto scatter = [&](uint32_t t0, int j, uint32_t a, uint32_t b) {
+                for (uint32_t k = a > t0 ? a : t0; k < b && k - t0 <= kTile; k++)
+                    S.owner[k - t0] = (uint16_t)((j * kThreads + tid) | (k == a ? kOwnFirst : 0u) | (k + 1u == b ? kOwnLast : 0u));
+            };
+            if (!last) {
+                const uint32_t f0 = (c0 + i) * kChunk;
+                const uint32_t f_end = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
+                kb0 = B.frag_blk_off[f0]; kb1 = B.frag_blk_off[f_end];
+                kb0 = kb0 < B.n_blk ? kb0 : B.n_blk;
+                kb1 = kb1 < B.n_blk ? kb1 : B.n_blk;
+                if (kb1 < kb0) kb1 = kb0;
+                uint32_t chr[kFPL], fs[kFPL], fe[kFPL], o0[kFPL], o1[kFPL], flg[kFPL];
+#pragma unroll
+                for (int j = 0; j < kFPL; j++) {
+                    chr[j] = fc_next.chr[j]; fs[j] = fc_next.fs[j]; fe[j] = fc_next.fe[j];
+                    o0[j] = fc_next.o0[j]; o1[j] = fc_next.o1[j]; flg[j] = fc_next.flg[j];
+                }
+                // the block columns of the wave's first strides are requested now as well
+#pragma unroll
+                for (int u = 0; u < kBU; u++) nxt[u] = load_cols(kb0 + (wave + u * kWaves) * kStride + lane);
+                u32x4 R[kFPL];
+                bool extent_ok[kFPL];
+                uint64_t gfs[kFPL], gfe[kFPL];
+#pragma unroll
+                for (int j = 0; j < kFPL; j++) {
+                    const uint32_t f = f0 + j * kThreads + tid;
+                    const bool in = f < B.n_frag;
+                    // the CSR offsets (host batches were checked by irf_submit_batch; device-resident ones are checked here): inside
+                    // the array's bounds, non-decreasing, spanning [0, n_blk].  Clamped, they address nothing out of bounds.
+                    if (in && (o0[j] > B.n_blk || o1[j] > B.n_blk || o1[j] < o0[j] || (f == 0u && o0[j] != 0u) || (f == B.n_frag - 1u && o1[j] != B.n_blk))) err |= ERR_CSR;
+                    uint32_t o0c = o0[j] < B.n_blk ? o0[j] : B.n_blk, o1c = o1[j] < B.n_blk ? o1[j] : B.n_blk;
+                    if (!in) { o0c = 0; o1c = 0; }
+                    scatter(kb0, j, o0c, o1c);
+                    const bool chr_ok = in && chr[j] < n_chr;
+                    if (in && !chr_ok) err |= ERR_CHR_RANGE;
+                    u32x4 rec = S.chrtab[chr_ok && chr[j] < kChrTab ? chr[j] : 0u];
+                    if (chr_ok && chr[j] >= kChrTab) rec = chr_rec[chr[j]];
+                    const bool counted = chr_ok && rec.w != 0u;
+                    const uint64_t base = (uint64_t)rec.y << 32 | rec.x;
+                    const uint32_t clen = rec.z;
+                    const uint32_t fdir = flg[j] & 1u;
+                    roi_row[j] = fdir << 31;
+                    S.facts[j * kThreads + tid] = counted ? make_uint2((uint32_t)(base >> 6) | (fdir ? kFragDir : 0u) | kFragValid, clen) : make_uint2(0u, 0u);
+                    // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment.  The
+                    // record is requested here and looked at below
+                    extent_ok[j] = n_roi_dev != 0u && counted && fs[j] <= fe[j] && fe[j] <= clen;
+                    gfs[j] = base + fs[j]; gfe[j] = base + fe[j];
+                    R[j] = roi_bkt[extent_ok[j] ? gfe[j] >> kBucketShift : 0ull];
+                    // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
+                    const uint32_t k = counted ? chr[j] * 2u + fdir : kEmpty;
                     uint64_t todo = __ballot(k != kEmpty);
                     while (todo) {
                         const int lead = __ffsll((long long)todo) - 1;
@@ -711,150 +657,182 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
                         if ((int)lane == lead) {
                             const uint32_t n = (uint32_t)__popcll(same);
                             if (lk < kChrBins) atomicAdd(&S.chr[lk], n);
-                            else chr_over = kOqRoi | 1ull << 60 | (unsigned long long)n << 32 | lk;
+                            else add_u32(T.chr_cnt + lk, n);        // (a reference beyond the LDS histogram: this wave pays for the atomic)
                         }
                         todo &= ~same;
                     }
                 }
-                if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);      // (in flight under the block phase)
-                // the block columns of the wave's first strides are requested in front of the barrier
-                Cols nxt[kBU];
 #pragma unroll
-                for (int u = 0; u < kBU; u++) nxt[u] = load_cols(kb0 + (wave + u * kWorkers) * kStride + lane);
-                CPROF(1);
-                wg_barrier();               // ---- facts and owners of chunk i are in place, the flushed cells are zero ----
-                CPROF(2);
-
-                {
-                    uint32_t q = R.z & 0x0fffffffu;
-                    if (extent_ok && q < n_roi_dev) {
-                        uint64_t rgs = (uint64_t)((R.z >> 28) & 3u) << 32 | R.x;
-                        const uint64_t rge = (uint64_t)(R.z >> 30) << 32 | R.y;
-                        uint32_t row = R.w;
+                for (int j = 0; j < kFPL; j++) {
+                    const uint32_t fdir31 = roi_row[j];
+                    roi_row[j] = kEmpty;
+                    uint32_t q = R[j].z & 0x0fffffffu;
+                    if (extent_ok[j] && q < n_roi_dev) {
+                        uint64_t rgs = (uint64_t)((R[j].z >> 28) & 3u) << 32 | R[j].x;
+                        const uint64_t rge = (uint64_t)(R[j].z >> 30) << 32 | R[j].y;
+                        uint32_t row = R[j].w;
                         bool have = true;
-                        if (rge < gfe) {              // several ROIs end inside the bucket before the fragment does
+                        if (rge < gfe[j]) {           // several ROIs end inside the bucket before the fragment does
                             q++;
-                            while (q < n_roi_dev && gp(T.roi_gend)[q] < gfe) q++;
+                            while (q < n_roi_dev && gp(T.roi_gend)[q] < gfe[j]) q++;
                             have = q < n_roi_dev;
                             if (have) { rgs = gp(T.roi_gstart)[q]; row = gp(T.roi_idx)[q]; }
                         }
-                        if (have && rgs <= gfs) cache_add<kRCache>(T, S, S.rtag, S.rcnt, S.rlist, &S.rl_n, row, dir, kOqRoi);
+                        if (have && rgs <= gfs[j]) roi_row[j] = row | fdir31;
                     }
                 }
-                if (chr_over) oq_push(T, S, chr_over);
-                // ---------------- B. block phase: one block per lane and stride of 63, kBU strides at once ----------------
-                const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
-                const uint32_t win5 = (uint32_t)(win >> 5);
-                uint32_t wmax = 0;
-                for (uint32_t t0 = kb0; t0 < kb1;) {
-                    const uint32_t tile_n = kb1 - t0 < kTile ? kb1 - t0 : kTile;
-                    const uint32_t n_str = (tile_n + kStride - 1u) / kStride;
-                    for (uint32_t s0 = wave; s0 < n_str; s0 += kWorkers * kBU) {
-                        // (a stride beyond the tile's last does nothing: `here` is false in every lane)
-                        Cols cur[kBU];
-                        uint32_t ti[kBU], ow[kBU], fb[kBU], clen_b[kBU], be[kBU], bdir[kBU];
-                        bool here[kBU], own[kBU], ok[kBU];
-                        u32x4 rs[kBU], re[kBU], je[kBU];
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) {
-                            ti[u] = (s0 + u * kWorkers) * kStride + lane;
-                            cur[u] = nxt[u];
-                            nxt[u] = load_cols(t0 + ti[u] + kWorkers * kBU * kStride);        // (the next pass, requested now)
-                            here[u] = t0 + ti[u] < kb1 && ti[u] <= kTile;        // the block exists and has an owner entry in this tile
-                            own[u] = here[u] && lane < kStride && ti[u] < tile_n;
-                            ow[u] = S.owner[here[u] ? ti[u] : 0u];
-                        }
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) {
-                            const uint2 fa = S.facts[ow[u] & kOwnMask];
-                            fb[u] = here[u] ? fa.x : 0u; clen_b[u] = fa.y;
-                        }
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) {
-                            const uint32_t bs = cur[u].bs;
-                            be[u] = bs + cur[u].bl;
-                            const bool in_range = be[u] >= bs && be[u] <= clen_b[u];
-                            const bool valid = (fb[u] & kFragValid) != 0u;
-                            if (own[u] && valid && !in_range) err |= ERR_BLOCK_RANGE;
-                            ok[u] = valid && in_range;
-                            bdir[u] = (fb[u] & kFragDir) ? 1u : 0u;
-                            const uint32_t cbase = (fb[u] & kFragBaseMask) << 1;      // base >> 5
-                            // the two cell records: plane coordinates of start and end, point ranks of both range ends
-                            rs[u] = cell_s[ok[u] ? cbase + (bs >> kCellShift) : 0u];
-                            re[u] = cell_e[ok[u] ? cbase + (be[u] >> kCellShift) : 0u];
-                        }
-                        uint32_t bs1[kBU], span[kBU], klo[kBU], khi[kBU], slot[kBU], rsz1[kBU];
-                        uint64_t gbe[kBU];
-                        bool has_next[kBU], jc[kBU];
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) {
-                            // the successor (next lane): junction to the right of the block — both flanks long enough, same read,
-                            // same fragment
-                            bs1[u] = from_next_lane(cur[u].bs);
-                            const uint32_t bl1 = from_next_lane(cur[u].bl), rd1 = from_next_lane(cur[u].rd);
-                            const bool ok1 = from_next_lane(ok[u] ? 1u : 0u) != 0u;
-                            has_next[u] = own[u] && ok[u] && !(ow[u] & kOwnLast) && ok1;
-                            jc[u] = has_next[u] && rd1 == cur[u].rd && cur[u].bl >= junc_min_flank && bl1 >= junc_min_flank;
-                            span[u] = bs1[u] - be[u];
-                            if (jc[u] && (bs1[u] < be[u] || span[u] >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[u] = false; }
-                            gbe[u] = ((uint64_t)(fb[u] & kFragBaseMask) << 6) + be[u];
-                            klo[u] = ((uint32_t)gbe[u] << kJuncSpanBits) | span[u];
-                            khi[u] = (uint32_t)(gbe[u] >> (32 - kJuncSpanBits));
-                            slot[u] = junction_hash(klo[u], khi[u]) & jh_mask;
-                            je[u] = jhash[jc[u] ? slot[u] : 0u];
-                            asm volatile("" : "+v"(je[u].z));       // (the row comes with the key, not in a second load behind the compare)
-                        }
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) rsz1[u] = from_next_lane(rs[u].z);
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) {
-                            const uint32_t bs = cur[u].bs, bl = cur[u].bl;
-                            // known junction?  (the probe continues only past a slot another key holds: load <= 1/32)
-                            bool hit = jc[u] && je[u].x == klo[u] && je[u].y == khi[u];
-                            {
-                                bool more = jc[u] && !hit && (je[u].x & je[u].y) != kEmpty;
-                                while (more) {
-                                    slot[u] = (slot[u] + 1u) & jh_mask;
-                                    je[u] = jhash[slot[u]];
-                                    hit = je[u].x == klo[u] && je[u].y == khi[u];
-                                    more = !hit && (je[u].x & je[u].y) != kEmpty;
-                                }
-                            }
-                            // JunctionCount: a known junction's counter also stands for the read's two difference events here
-                            if (hit) cache_add<kJCache>(T, S, S.jtag, S.jcnt, S.jlist, &S.jl_n, je[u].z, bdir[u], kOqKnown);
-                            if (jc[u] && !hit) novel_add(T, S, (gbe[u] << kJuncLeftShift) | ((unsigned long long)span[u] << 1) | bdir[u], lane, err);
-                            // CoverageBlocks / FragmentsMap: the block's end, its successor's start (unless the junction between
-                            // them was counted on a known junction), and its own start if it opens the fragment
-                            depth_event(T, S, win5, use_win, re[u].z, be[u] & 31u, bdir[u], -1, own[u] && ok[u] && !hit, lane, wmax);
-                            depth_event(T, S, win5, use_win, rsz1[u], bs1[u] & 31u, bdir[u], 1, has_next[u] && !hit, lane, wmax);
-                            depth_event(T, S, win5, use_win, rs[u].z, bs & 31u, bdir[u], 1, own[u] && ok[u] && (ow[u] & kOwnFirst) != 0u, lane, wmax);
-                            // SpansPoint: the points in [bs + sp_lo_add, be - sp_hi_sub] are n1 - n0 points with consecutive rows
-                            if (own[u] && ok[u] && bl > sp_min_len) {
-                                const uint32_t skip = (uint32_t)__popc(rs[u].y & ((1u << (bs & 31u)) - 1u));
-                                const uint32_t n0 = rs[u].x + skip;
-                                const uint32_t n1 = re[u].x + (uint32_t)__popc(re[u].y & ((1u << (be[u] & 31u)) - 1u));
-                                const uint32_t row0 = rs[u].w + skip;
-                                for (uint32_t p = n0; p < n1; p++) cache_add<kPCache>(T, S, S.ptag, S.pcnt, S.plist, &S.pl_n, row0 + (p - n0), bdir[u], kOqPoint);
-                            }
-                        }
-                    }
-                    t0 += kTile;
-                    if (t0 < kb1) {         // a chunk with more blocks than one tile holds: the next tile's owners
-                        wg_barrier();
-                        scatter(t0);
-#pragma unroll
-                        for (int u = 0; u < kBU; u++) nxt[u] = load_cols(t0 + (wave + u * kWorkers) * kStride + lane);
-                        wg_barrier();
-                    }
-                }
-                wmax = wave_max_dpp(wmax);
-                if (lane == 63u && wmax) atomicMax(&S.wmax[i & 1u], wmax);
             }
+            CPROF(1);
+            // ---------------- the flush: every load above has landed, nothing is waited for until the barrier ----------------
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flush_window(T, S, win_old, flush_to, lane, wave, s_cstat_local);
+            for (uint32_t e = tid; e < n_oq; e += kThreads) oq_apply(T, S.oq[(i + 1u) & 1u][e]);
+            CSTAT(3, wave == 0u ? n_oq : 0u); CSTAT(6, wave == 0u ? 1u : 0u);
+            if (do_caches) {
+                CSTAT(5, wave == 0u ? 1u : 0u);
+                const uint32_t n_l = S.ll_n, n_j = S.jl_n, n_p = S.pl_n, n_r = S.rl_n;
+                flush_lines(T, S, n_l, lane, wave, s_cstat_local);
+                flush_cache<kJCache>(S.jtag, S.jcnt, S.jlist, n_j, T.known_cnt, T.n_kj, tid);
+                flush_cache<kPCache>(S.ptag, S.pcnt, S.plist, n_p, T.sp_cnt, T.n_sp, tid);
+                flush_cache<kRCache>(S.rtag, S.rcnt, S.rlist, n_r, T.roi_cnt, T.n_roi, tid);
+                if (wave == kWaves - 1u) flush_novel(T, S, lane, err);
+                wg_barrier();           // (every wave has read the counts of claimed slots)
+                if (tid == 0) { S.ll_n = 0; S.jl_n = 0; S.pl_n = 0; S.rl_n = 0; }
+            }
+            CPROF(2);
+            if (last) break;            // (the slice's accumulators are empty again)
+#ifndef K_NO_PREFETCH
+            if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);      // (in flight under the block phase)
+#endif
+            wg_barrier();               // ---- facts and owners of chunk i are in place, the flushed cells are zero ----
+            CPROF(4);
+
+            // ---------------- B. block phase: one block per lane and stride of 63, kBU strides at once ----------------
+#pragma unroll
+            for (int j = 0; j < kFPL; j++)
+                if (roi_row[j] != kEmpty) cache_add<kRCache>(T, S, S.rtag, S.rcnt, S.rlist, &S.rl_n, roi_row[j] & 0x7fffffffu, roi_row[j] >> 31, kOqRoi);
+            const bool use_win = kb1 - kb0 <= kWinMaxBlocks;
+            if (use_win) ev_since += 2u * (kb1 - kb0);
+            const uint32_t win5 = (uint32_t)(win >> 5);
+            uint32_t wmax = 0;
+            for (uint32_t t0 = kb0; t0 < kb1;) {
+                const uint32_t tile_n = kb1 - t0 < kTile ? kb1 - t0 : kTile;
+                const uint32_t n_str = (tile_n + kStride - 1u) / kStride;
+                for (uint32_t s0 = wave; s0 < n_str; s0 += kWaves * kBU) {
+                    // (a stride beyond the tile's last does nothing: `here` is false in every lane)
+                    Cols cur[kBU];
+                    uint32_t ti[kBU], ow[kBU], fb[kBU], clen_b[kBU], be[kBU], bdir[kBU];
+                    bool here[kBU], own[kBU], ok[kBU];
+                    u32x4 rs[kBU], re[kBU], je[kBU];
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        ti[u] = (s0 + u * kWaves) * kStride + lane;
+                        cur[u] = nxt[u];
+                        nxt[u] = load_cols(t0 + ti[u] + kWaves * kBU * kStride);        // (the next pass, requested now)
+                        here[u] = t0 + ti[u] < kb1 && ti[u] <= kTile;        // the block exists and has an owner entry in this tile
+                        own[u] = here[u] && lane < kStride && ti[u] < tile_n;
+                        ow[u] = S.owner[here[u] ? ti[u] : 0u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        const uint2 fa = S.facts[ow[u] & kOwnMask];
+                        fb[u] = here[u] ? fa.x : 0u; clen_b[u] = fa.y;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        const uint32_t bs = cur[u].bs;
+                        be[u] = bs + cur[u].bl;
+                        const bool in_range = be[u] >= bs && be[u] <= clen_b[u];
+                        const bool valid = (fb[u] & kFragValid) != 0u;
+                        if (own[u] && valid && !in_range) err |= ERR_BLOCK_RANGE;
+                        ok[u] = valid && in_range;
+                        bdir[u] = (fb[u] & kFragDir) ? 1u : 0u;
+                        const uint32_t cbase = (fb[u] & kFragBaseMask) << 1;      // base >> 5
+                        // the two cell records: plane coordinates of start and end, point ranks of both range ends
+                        rs[u] = cell_s[ok[u] ? cbase + (bs >> kCellShift) : 0u];
+                        re[u] = cell_e[ok[u] ? cbase + (be[u] >> kCellShift) : 0u];
+                    }
+                    uint32_t bs1[kBU], span[kBU], klo[kBU], khi[kBU], slot[kBU], rsz1[kBU];
+                    uint64_t gbe[kBU];
+                    bool has_next[kBU], jc[kBU];
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        // the successor (next lane): junction to the right of the block — both flanks long enough, same read,
+                        // same fragment
+                        bs1[u] = from_next_lane(cur[u].bs);
+                        const uint32_t bl1 = from_next_lane(cur[u].bl), rd1 = from_next_lane(cur[u].rd);
+                        const bool ok1 = from_next_lane(ok[u] ? 1u : 0u) != 0u;
+                        has_next[u] = own[u] && ok[u] && !(ow[u] & kOwnLast) && ok1;
+                        jc[u] = has_next[u] && rd1 == cur[u].rd && cur[u].bl >= junc_min_flank && bl1 >= junc_min_flank;
+                        span[u] = bs1[u] - be[u];
+                        if (jc[u] && (bs1[u] < be[u] || span[u] >= (1u << kJuncSpanBits))) { err |= ERR_JUNC_RANGE; jc[u] = false; }
+                        gbe[u] = ((uint64_t)(fb[u] & kFragBaseMask) << 6) + be[u];
+                        klo[u] = ((uint32_t)gbe[u] << kJuncSpanBits) | span[u];
+                        khi[u] = (uint32_t)(gbe[u] >> (32 - kJuncSpanBits));
+                        slot[u] = junction_hash(klo[u], khi[u]) & jh_mask;
+                        je[u] = jhash[jc[u] ? slot[u] : 0u];
+                        asm volatile("" : "+v"(je[u].z));       // (the row comes with the key, not in a second load behind the compare)
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) rsz1[u] = from_next_lane(rs[u].z);
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) {
+                        const uint32_t bs = cur[u].bs, bl = cur[u].bl;
+                        // known junction?  (the probe continues only past a slot another key holds: load <= 1/32)
+                        bool hit = jc[u] && je[u].x == klo[u] && je[u].y == khi[u];
+                        {
+                            bool more = jc[u] && !hit && (je[u].x & je[u].y) != kEmpty;
+                            while (more) {
+                                slot[u] = (slot[u] + 1u) & jh_mask;
+                                je[u] = jhash[slot[u]];
+                                hit = je[u].x == klo[u] && je[u].y == khi[u];
+                                more = !hit && (je[u].x & je[u].y) != kEmpty;
+                            }
+                        }
+                        // JunctionCount: a known junction's counter also stands for the read's two difference events here
+                        if (hit) cache_add<kJCache>(T, S, S.jtag, S.jcnt, S.jlist, &S.jl_n, je[u].z, bdir[u], kOqKnown);
+                        if (jc[u] && !hit) novel_add(T, S, (gbe[u] << kJuncLeftShift) | ((unsigned long long)span[u] << 1) | bdir[u], lane, err);
+                        // CoverageBlocks / FragmentsMap: the block's end, its successor's start (unless the junction between
+                        // them was counted on a known junction), and its own start if it opens the fragment
+                        depth_event(T, S, win5, use_win, re[u].z, be[u] & 31u, bdir[u], -1, own[u] && ok[u] && !hit, lane, wmax);
+                        depth_event(T, S, win5, use_win, rsz1[u], bs1[u] & 31u, bdir[u], 1, has_next[u] && !hit, lane, wmax);
+                        depth_event(T, S, win5, use_win, rs[u].z, bs & 31u, bdir[u], 1, own[u] && ok[u] && (ow[u] & kOwnFirst) != 0u, lane, wmax);
+                        // SpansPoint: the points in [bs + sp_lo_add, be - sp_hi_sub] are n1 - n0 points with consecutive rows
+                        if (own[u] && ok[u] && bl > sp_min_len) {
+                            const uint32_t skip = (uint32_t)__popc(rs[u].y & ((1u << (bs & 31u)) - 1u));
+                            const uint32_t n0 = rs[u].x + skip;
+                            const uint32_t n1 = re[u].x + (uint32_t)__popc(re[u].y & ((1u << (be[u] & 31u)) - 1u));
+                            const uint32_t row0 = rs[u].w + skip;
+                            for (uint32_t p = n0; p < n1; p++) cache_add<kPCache>(T, S, S.ptag, S.pcnt, S.plist, &S.pl_n, row0 + (p - n0), bdir[u], kOqPoint);
+                        }
+                    }
+                }
+                t0 += kTile;
+                if (t0 < kb1) {         // a chunk with more blocks than one tile holds: the next tile's owners
+                    wg_barrier();
+#pragma unroll
+                    for (int j = 0; j < kFPL; j++) {        // (the offsets once more: not kept in registers for this rare case)
+                        const uint32_t f = (c0 + i) * kChunk + j * kThreads + tid;
+                        if (f < B.n_frag) {
+                            const uint32_t a = B.frag_blk_off[f], b = B.frag_blk_off[f + 1u];
+                            scatter(t0, j, a < B.n_blk ? a : B.n_blk, b < B.n_blk ? b : B.n_blk);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBU; u++) nxt[u] = load_cols(t0 + (wave + u * kWaves) * kStride + lane);
+                    wg_barrier();
+                }
+            }
+            wmax = wave_max_dpp(wmax);
+            if (lane == 63u && wmax) atomicMax(&S.wmax[i & 1u], wmax);
+#ifdef K_NO_PREFETCH
+            if (i + 1u < nc) fc_next = load_frag(c0 + i + 1u);
+#endif
         }
     }
 #ifdef COUNT_PROF
-    if (lane == 0u && wave >= kWorkers) for (int k = 0; k < 8; k++) atomicAdd(&g_cstat[k], (unsigned long long)s_cstat_local[k]);
-    if (lane == 0u && prof_on && blockIdx.x < 2048u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][wave == 0u ? 0 : (wave == kWorkers ? 2 : 1)][k] = prof_acc[k];
+    if (lane == 0u && wave == 0u) for (int k = 0; k < 8; k++) atomicAdd(&g_cstat[k], (unsigned long long)s_cstat_local[k]);
+    if (lane == 0u && prof_on && blockIdx.x < 2048u) for (int k = 0; k < 8; k++) g_cprof[blockIdx.x][wave == 0u ? 0 : 1][k] = prof_acc[k];
 #endif
     if (err) __hip_atomic_fetch_or(gp(T.err_flags), err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wg_barrier();
@@ -1017,13 +995,13 @@ void launch_count(const CountTables& T, CountTables* d_T, CountTables* shadow, c
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cstat), zero, sizeof zero);
         fprintf(stderr, "count_stat: chunks %llu, window steps looked at %llu, not empty %llu, line steps not empty %llu, queue entries %llu, jumps %llu, cache flushes %llu\n",
                 st[6], st[0], st[1], st[2], st[3], st[4], st[5]);
-        const char* who[3] = {"worker 0", "last worker", "flusher"};
-        for (int w = 0; w < 3; w++) {
+        const char* who[2] = {"wave 0", "last wave"};
+        for (int w = 0; w < 2; w++) {
             double a[8] = {0};
             for (uint32_t b = 0; b < blocks && b < 2048u; b++) for (int k = 0; k < 8; k++) a[k] += h[b][w][k];
             const double n = blocks < 2048u ? blocks : 2048u;
-            fprintf(stderr, "count_prof %s, 10 ns ticks per workgroup: wait at barrier 1 %.0f | fragment phase / flushes %.0f | wait at barrier 2 %.0f | block phase / idle %.0f\n",
-                    who[w], a[0] / n, a[1] / n, a[2] / n, a[3] / n);
+            fprintf(stderr, "count_prof %s, 10 ns ticks per workgroup: wait at barrier 1 %.0f | fragment phase %.0f | flush %.0f | wait at barrier 2 %.0f | block phase %.0f\n",
+                    who[w], a[0] / n, a[1] / n, a[2] / n, a[4] / n, a[3] / n);
         }
     }
 #endif
