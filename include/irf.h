@@ -452,14 +452,16 @@ int irf_copy_to_host(void* dst_host, const void* src_device, size_t bytes);
 int irf_gpu_bgzf_inflate(int device, const uint8_t* bgzf, size_t len, uint8_t* out, size_t out_cap, size_t* out_len);
 
 /* Variant of irf_gpu_bgzf_inflate that allocates nothing.  It has no counterpart in the reference: it exists for
- * callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
- * allocation).  Same members in (host memory), same checks and status codes, but the inflated bytes are left in
- * CALLER-owned DEVICE memory `out_device` (out_cap >= inflated size + 64: the inflate kernel stores whole words), and
- * the device staging the other entry point allocates per call (compressed bytes, member table, per-member status)
- * lives in a file-scope device array of the library (9 MiB per GPU, held until the process ends).  Limits:
+ * callers that cannot call hipMalloc (tight serving loops, phases in which the caller's allocator is frozen, harnesses
+ * that forbid allocation).  It is NOT itself capturable into a HIP graph: it copies synchronously on the null stream
+ * and reads a status word back.  Same members in (host memory), same checks and status codes, but the inflated bytes
+ * are left in CALLER-owned DEVICE memory `out_device` (out_cap >= inflated size + 64: the inflate kernel stores whole
+ * words), and the device staging the other entry point allocates per call (compressed bytes, member table, per-member
+ * status) lives in a file-scope device array of the library (9 MiB per GPU, held until the process ends).  Limits:
  * len <= IRF_NOALLOC_MAX_BYTES and at most IRF_NOALLOC_MAX_MEMBERS members, else IRF_E_RANGE (*out_len is still the size
- * needed when only out_cap is too small).  Calls no hipMalloc / hipFree.  Every call on a GPU shares that GPU's array:
- * calls that overlap on one GPU race — serialise them.  Synchronous (returns after the CRC check).               */
+ * needed when only out_cap is too small).  Calls no hipMalloc / hipFree.  Every call on a GPU shares that GPU's array,
+ * which keeps the last call's contents; calls from several host threads on one GPU are serialised by a per-device
+ * mutex held for the whole (synchronous) call, so they queue rather than race.  Synchronous (returns after the CRC check).               */
 #define IRF_NOALLOC_MAX_BYTES   (8u << 20)
 #define IRF_NOALLOC_MAX_MEMBERS 8192u
 int irf_gpu_bgzf_inflate_noalloc(int device, const uint8_t* bgzf, size_t len, uint8_t* out_device, size_t out_cap, size_t* out_len);

@@ -784,7 +784,7 @@ int irf_gpu_bgzf_inflate_noalloc(int device, const uint8_t* bgzf, size_t len, ui
     if (len > IRF_NOALLOC_MAX_BYTES) return IRF_E_RANGE;          // beyond the scratch array's staging area
     if (hipSetDevice(device) != hipSuccess) return IRF_E_DEVICE;
     NaDevice& D = g_na[device];
-    std::lock_guard<std::mutex> lock(D.mu);                       // (host state only: calls that overlap on one GPU still share the array)
+    std::lock_guard<std::mutex> lock(D.mu);                       // held to the end of this synchronous call: callers on one GPU queue
     if (!D.scratch) {
         // this device's copy of the array; the name `na_scratch` itself is only a host-side handle
         uint8_t* ptr = nullptr;

@@ -89,8 +89,11 @@ struct irf_ctx {
     }
     hipStream_t junc_stream = nullptr;           // the novel-junction sort of irf_finalize, next to the statistics kernels
     hipEvent_t ev_junc_done = nullptr;
+    hipEvent_t ev_scalars = nullptr;             // irf_finalize: the scalars and error flags have reached h_scal
+    unsigned long long* h_scal = nullptr;        // page-locked: d_scalars[0..8), then the error flags
     std::string err;
     bool have_map = false, finalized = false, results_ready = false;
+    bool gathered = false;                       // irf_gather added the peers' columns to this context's (once per sample)
     bool kj_depth_applied = false;               // the known-junction difference events of this sample are in the planes (finalize may be called again after a failure)
 
     // ---- chromosome map ----
@@ -296,6 +299,9 @@ int irf_ctx::init() {
         HIP_TRY(hipStreamCreateWithPriority(&junc_stream, hipStreamNonBlocking, greatest));
         HIP_TRY(hipStreamCreateWithPriority(&clear_stream, hipStreamNonBlocking, least));      // (yields to the export's copy kernels)
         HIP_TRY(hipEventCreate(&ev_junc_done));
+        HIP_TRY(hipEventCreateWithFlags(&ev_scalars, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&h_scal, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+        memset(h_scal, 0, 16 * sizeof(unsigned long long));
         HIP_TRY(hipStreamCreateWithFlags(&export_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ev_tables_ready, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_export_done, hipEventDisableTiming));
@@ -326,6 +332,8 @@ void irf_ctx::free_events() {
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
     if (ev_junc_done) { (void)hipEventDestroy(ev_junc_done); ev_junc_done = nullptr; }
+    if (ev_scalars) { (void)hipEventDestroy(ev_scalars); ev_scalars = nullptr; }
+    if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
     if (export_stream) { (void)hipStreamSynchronize(export_stream); (void)hipStreamDestroy(export_stream); export_stream = nullptr; }
     if (ev_tables_ready) { (void)hipEventDestroy(ev_tables_ready); ev_tables_ready = nullptr; }
     if (ev_export_done) { (void)hipEventDestroy(ev_export_done); ev_export_done = nullptr; }
@@ -338,6 +346,9 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipStreamSynchronize(copy_stream));
+    // exports of the last sample may still be reading the tables that are reallocated below
+    if (export_stream) HIP_TRY(hipStreamSynchronize(export_stream));
+    exports_pending = false;
     n_chr = n;
     slot_names.clear();
     chr_len.assign(lens, lens + n);
@@ -739,6 +750,7 @@ int irf_ctx::zero_counters() {
     n_fragments = n_blocks = junc_upper = 0;
     n_unique = n_events = 0;
     finalized = results_ready = false;
+    gathered = false;
     kj_depth_applied = false;
     ir_prepared[0] = ir_prepared[1] = false;
     imp_junc.clear();
@@ -920,7 +932,7 @@ int irf_ctx::reorder(dev::BatchDev& B) {
     }
     dev::launch_reorder_frags(B.n_frag, ro_frag_recs.p, ks, ro_chr.p, ro_flags.p, ro_start.p, ro_end.p, ro_nblk.p, ro_src_off.p, stream);
     dev::launch_exclusive_scan_u32(ro_nblk.p, ro_off.p, n + 1, d_ws_sort.p, stream);
-    dev::launch_reorder_blocks(B.n_frag, ro_blk_recs.p, ro_src_off.p, ro_off.p, ro_bs.p, ro_bl.p, ro_rd.p, stream);
+    dev::launch_reorder_blocks(B.n_frag, B.n_blk, ro_blk_recs.p, ro_src_off.p, ro_off.p, ro_bs.p, ro_bl.p, ro_rd.p, stream);
     HIP_TRY(hipGetLastError());
     B.frag_chr = ro_chr.p; B.frag_flags = ro_flags.p; B.frag_start = ro_start.p; B.frag_end = ro_end.p; B.frag_blk_off = ro_off.p;
     B.blk_start = ro_bs.p; B.blk_len = ro_bl.p; B.blk_read = ro_rd.p;
@@ -979,26 +991,13 @@ int irf_ctx::finalize() {
     dev::launch_exclusive_scan_u32(d_seg_sum.p, d_carry.p, 2 * plane_stride / dev::kDepthSegment, d_ws.p, stream);
     HIP_TRY(hipEventRecord(ev[1], stream));
     // (the vote came with the known-junction depth events: irf_reset zeroed the two sums, the kernel runs once per sample)
-    unsigned long long scal[8];
-    uint32_t errf = 0;
-    HIP_TRY(hipMemcpyAsync(scal, d_scalars.p, sizeof scal, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&errf, d_err.p, sizeof errf, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (errf) {
-        char m[160];
-        snprintf(m, sizeof m, "count kernel reported input errors (flags 0x%x: 1 chr id, 2 block beyond chromosome, 4 junction range, 8 junction capacity, 32 frag_blk_off of a device batch)", errf);
-        return fail(errf & dev::ERR_JUNC_CAPACITY ? IRF_E_STATE : ((errf & dev::ERR_CSR) ? IRF_E_ARG : IRF_E_RANGE), m);
-    }
-    n_events = scal[0];
-    votes[0] = scal[3]; votes[1] = scal[4];
-    if (n_events > 0xffffffffull) return fail(IRF_E_RANGE, "more than 2^32-1 junction records");
-    n_unique = 0;
-    d_sorted = d_junc_a.p;
-    uint32_t n_radix_passes = 0;
-    // JunctionCount::Directional() (OQ-5): known junctions only, so the vote is in
-    directionality = 0;
-    if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
-    else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
+    // The scalars the host needs (records in the junction buffer, the vote, the error flags) are copied to page-locked
+    // memory behind the scan, and the statistics kernels are queued BEHIND that copy before the host waits for it: they
+    // take the strandedness decision themselves from the vote in device memory (kernels.h: IntronTables::vote), so the
+    // device has 1.8 ms of work queued while the host reads the scalars and sets up the junction sort.
+    HIP_TRY(hipMemcpyAsync(h_scal, d_scalars.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_scal + 8, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ev_scalars, stream));
     // ---- per-intron statistics ----
     // The statistics kernels (1.9 ms of plane reads at 50 M pairs) need nothing from the novel junctions except in the last
     // columns of a row, and the sort-reduce of the novel junctions is ~40 small kernels and two host round trips that
@@ -1006,10 +1005,38 @@ int irf_ctx::finalize() {
     // writes the junction-dependent columns of the rows when both have finished.
     TRY(order_after_exports());
     HIP_TRY(hipEventRecord(ev[4], stream));
-    if (directionality != 0) launch_stats(0, directionality, true);      // both IR tables from one pass over the planes
-    else launch_stats(0, 0);
+    {
+        // both shapes are queued; the one that does not fit the vote returns at once (a few microseconds)
+        dev::IntronTables one = intron_tables(0, 0, false), two = intron_tables(0, 1, true);
+        one.vote = two.vote = d_scalars.p + 3;
+        one.dir_ratio = two.dir_ratio = P.dir_ratio;
+        dev::launch_intron_stats(one, stats_classes, stream);
+        dev::launch_intron_stats(two, stats_classes, stream);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[5], stream));
+    HIP_TRY(hipEventSynchronize(ev_scalars));
+    const unsigned long long* scal = h_scal;
+    const uint32_t errf = (uint32_t)h_scal[8];
+    if (errf) {
+        (void)hipStreamSynchronize(stream);      // (the statistics of the refused sample: nothing reads them)
+        char m[160];
+        snprintf(m, sizeof m, "count kernel reported input errors (flags 0x%x: 1 chr id, 2 block beyond chromosome, 4 junction range, 8 junction capacity, 32 frag_blk_off of a device batch)", errf);
+        return fail(errf & dev::ERR_JUNC_CAPACITY ? IRF_E_STATE : ((errf & dev::ERR_CSR) ? IRF_E_ARG : IRF_E_RANGE), m);
+    }
+    n_events = scal[0];
+    votes[0] = scal[3]; votes[1] = scal[4];
+    if (n_events > 0xffffffffull) { (void)hipStreamSynchronize(stream); return fail(IRF_E_RANGE, "more than 2^32-1 junction records"); }
+    n_unique = 0;
+    d_sorted = d_junc_a.p;
+    uint32_t n_radix_passes = 0;
+    // JunctionCount::Directional() (OQ-5): known junctions only, so the vote is in.  (The same expression as in the
+    // statistics kernels, on the same two sums.)
+    directionality = 0;
+    if (votes[0] > votes[1] * (unsigned long long)P.dir_ratio) directionality = 1;
+    else if (votes[1] > votes[0] * (unsigned long long)P.dir_ratio) directionality = -1;
+    // the junction stream starts behind the count kernels and the scalars' copy (until now the host's wait ordered them)
+    HIP_TRY(hipStreamWaitEvent(junc_stream, ev_scalars, 0));
     struct StreamSwap {            // (the code below says `stream`: it runs on the junction stream until this goes out of scope)
         hipStream_t& ref; hipStream_t saved;
         StreamSwap(hipStream_t& r, hipStream_t to) : ref(r), saved(r) { ref = to; }
@@ -1094,12 +1121,14 @@ int irf_ctx::finalize() {
             PlaneSet& sp = spare[k];
             if (sp.clean) continue;
             const bool had = sp.allocated(plane_stride);
-            // a first spare set at once; the second one with it when the device has plenty of room (three more sets would
-            // still fit), else never
-            if (!had && k == 1) {
+            // a first spare set when it leaves room for what the next sample may still grow (junction buffers, the reorder
+            // copies: a set's size again, at least 1 GiB); the second one with it when the device has plenty of room (three
+            // more sets would still fit), else never
+            if (!had) {
                 size_t free_b = 0, total_b = 0;
                 const size_t set_b = (size_t)2 * plane_stride * sizeof(int32_t);
-                if (!spare[0].allocated(plane_stride) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * set_b) { (void)hipGetLastError(); continue; }
+                const size_t need_b = k == 0 ? set_b + std::max<size_t>(set_b, (size_t)1 << 30) : 3 * set_b;
+                if ((k == 1 && !spare[0].allocated(plane_stride)) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need_b) { (void)hipGetLastError(); continue; }
             }
             if (sp.diff.reserve(2 * plane_stride) != hipSuccess || sp.seg_sum.reserve(n_seg2) != hipSuccess ||
                 sp.dirty.reserve(dev::dirty_map_bytes(plane_stride)) != hipSuccess) {
@@ -1145,6 +1174,7 @@ int irf_ctx::finalize() {
     if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.table_ms = ms;       // launch_ir_rows
     if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) timing.total_finalize_ms = ms;
     finalized = true;
+    gathered = false;
     results_ready = false;
     return 0;
 }
@@ -1622,6 +1652,8 @@ int irf_gather(irf_ctx* const* ctxs, uint32_t n, uint32_t root) {
     if (!ctxs || n == 0 || root >= n) return IRF_E_ARG;
     for (uint32_t i = 0; i < n; i++) if (!ctxs[i]) return IRF_E_ARG;
     irf_ctx* R = ctxs[root];
+    // the peers' columns are ADDED to the root's: a second gather of the same sample would add them twice
+    if (R->gathered) return R->fail(IRF_E_STATE, "irf_gather: this sample was gathered already (irf_reset and count again, or read the results)");
     for (uint32_t i = 0; i < n; i++) {
         irf_ctx* c = ctxs[i];
         if (!c->finalized) return R->fail(IRF_E_STATE, "irf_gather: every context must be finalized");
@@ -1663,8 +1695,9 @@ int irf_gather(irf_ctx* const* ctxs, uint32_t n, uint32_t root) {
         std::vector<irf_ctx::ImpJunc> rows;
         TRY(c->own_novel_junctions(rows));
         R->imp_junc.insert(R->imp_junc.end(), rows.begin(), rows.end());
-        R->n_fragments += 0;       // (fragments SUBMITTED stay per context: every shard may have been fed the whole sample)
+        // (n_fragments, the fragments SUBMITTED, stays per context: every shard may have been fed the whole sample)
     }
+    R->gathered = true;
     R->results_ready = false;
     return 0;
 }

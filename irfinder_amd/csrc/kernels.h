@@ -149,7 +149,7 @@ void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n
 // nblk: n_frag + 1 elements (the last one 0: its exclusive scan is the new offsets array, total included)
 void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint64_t* sorted_keys, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
                           uint32_t* nblk, uint32_t* src_off, hipStream_t s);
-void launch_reorder_blocks(uint32_t n_frag, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
+void launch_reorder_blocks(uint32_t n_frag, uint32_t n_blk, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
                            hipStream_t s);
 
 // ---- scans ----------------------------------------------------------------
@@ -296,6 +296,12 @@ struct IntronTables {
     // parameters
     uint32_t trim_centre_pct, pct_interpolate, flank_offset, flank_len, flank_use_measured, warn_nonuniform_and;
     int32_t directionality;        // 0: non-directional table (both planes)
+    // vote != nullptr: the statistics kernels take the strandedness decision themselves from the two sums of the vote
+    // (JunctionCount::Directional(): same > opp * dir_ratio -> 1, opp > same * dir_ratio -> -1, else 0) instead of
+    // `directionality`, and a launch whose shape does not fit the decision returns at once: the single-table launch when
+    // the sample is stranded, the dual one when it is not.  The host queues both and reads the vote while they run.
+    const unsigned long long* vote;
+    uint32_t dir_ratio;
     double warn_lowcover_min, warn_lowsplice_min, warn_minor_ratio, warn_nonuniform_rel, warn_nonuniform_abs;
     // outputs
     double* out_f64;               // [8][n_intron]

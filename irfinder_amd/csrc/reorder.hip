@@ -64,8 +64,11 @@ __global__ __launch_bounds__(kThreads) void reorder_frags_kernel(uint32_t n_frag
     src_off[j] = r.off0;
 }
 
-// the blocks of the fragment now at j move to new_off[j]; four lanes per fragment (fragments have a handful of blocks)
-__global__ __launch_bounds__(kThreads) void reorder_blocks_kernel(uint32_t n_frag, const uint2* __restrict__ pk, const uint32_t* __restrict__ src_off,
+// the blocks of the fragment now at j move to new_off[j]; four lanes per fragment (fragments have a handful of blocks).
+// Offsets of a malformed device-resident batch (ranges that overlap: every one of them inside [0, n_blk], their sum beyond
+// it, or wrapped past 2^32) were reported as ERR_CSR by reorder_keys_kernel; here they must only stay inside the arrays:
+// reads are inside [0, n_blk) because off0 + nblk <= n_blk held per fragment, writes are cut at n_blk.
+__global__ __launch_bounds__(kThreads) void reorder_blocks_kernel(uint32_t n_frag, uint32_t n_blk, const uint2* __restrict__ pk, const uint32_t* __restrict__ src_off,
                                                                   const uint32_t* __restrict__ new_off, uint32_t* __restrict__ bs,
                                                                   uint32_t* __restrict__ bl, uint8_t* __restrict__ rd) {
     const uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void reorder_blocks_kernel(uint32_t n_fra
     const uint32_t src = src_off[j];
     const uint32_t dst = new_off[j], cnt = new_off[j + 1u] - dst;
     for (uint32_t k = (uint32_t)(t & 3u); k < cnt; k += 4u) {
+        if ((uint64_t)dst + k >= n_blk || (uint64_t)src + k >= n_blk) break;
         const uint2 v = pk[src + k];
         bs[dst + k] = v.x;
         bl[dst + k] = v.y & ((1u << kReadShift) - 1u);
@@ -98,10 +102,10 @@ void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint64_t
                        start, end, nblk, src_off);
 }
 
-void launch_reorder_blocks(uint32_t n_frag, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
+void launch_reorder_blocks(uint32_t n_frag, uint32_t n_blk, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
                            hipStream_t s) {
     const uint64_t threads = (uint64_t)n_frag * 4u;
-    hipLaunchKernelGGL(reorder_blocks_kernel, dim3((uint32_t)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, n_frag,
+    hipLaunchKernelGGL(reorder_blocks_kernel, dim3((uint32_t)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, n_frag, n_blk,
                        static_cast<const uint2*>(blk_recs), src_off, new_off, bs, bl, rd);
 }
 

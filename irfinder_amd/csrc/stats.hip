@@ -299,6 +299,12 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t k_begin = wg_off[blockIdx.x], k_end = wg_off[blockIdx.x + 1];
     if (k_begin >= k_end) return;
+    int dirn = T.directionality;
+    if (T.vote) {       // the decision is taken here (kernels.h); only the launch whose shape fits it goes on
+        const unsigned long long same = T.vote[0], opp = T.vote[1];
+        dirn = same > opp * (unsigned long long)T.dir_ratio ? 1 : (opp > same * (unsigned long long)T.dir_ratio ? -1 : 0);
+        if ((kTables == 2) != (dirn != 0)) return;
+    }
 #ifdef STATS_PROF
     unsigned long long prof_t = wall_clock64();
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -358,10 +364,10 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     const bool r_valid = (r_flags & 1u) != 0;
     const bool valid = r_valid && !(T.ablate & 1u);     // false: chromosome absent from the BAM header / not owned => depth 0 everywhere
     // the plane(s) a table reads: 2 = both strands (non-directional), else the intron's own strand under the vote
-    const int plane_strand = (((r_flags & 2u) != 0) == (T.directionality > 0)) ? 1 : 0;
+    const int plane_strand = (((r_flags & 2u) != 0) == (dirn > 0)) ? 1 : 0;
     int planes[kTables];
     if (kTables == 2) { planes[0] = 2; planes[kTables - 1] = plane_strand; }
-    else planes[0] = T.directionality != 0 ? plane_strand : 2;
+    else planes[0] = dirn != 0 ? plane_strand : 2;
     C.plane = kTables == 2 ? 2 : planes[0];                  // what the main pass loads
 
     // first / last flank_len nt of the intron, flank_offset nt inside it (full coordinates)

@@ -51,7 +51,8 @@ public:
     // Loads the four reference files (what the five loadRef calls of main() did).
     HipReadBlockProcessor(const char* ref_cover_bed, const char* ref_sj_ref, const char* ref_read_continues_ref,
                           const char* ref_roi_bed, int device = 0, const irf_params* params = nullptr,
-                          uint32_t batch_fragments = 1u << 20, uint32_t blocks_per_fragment_hint = 6) {
+                          uint32_t batch_fragments = 1u << 20, uint32_t blocks_per_fragment_hint = 6,
+                          uint32_t input_order = IRF_ORDER_ANY) {
         char err[256] = {0};
         irf_ref* ref = nullptr;
         int rc = irf_ref_load_files(ref_cover_bed, ref_sj_ref, ref_read_continues_ref, ref_roi_bed, &ref, err, sizeof err);
@@ -59,6 +60,13 @@ public:
         rc = irf_create(params, ref, device, &ctx_);
         irf_ref_free(ref);
         if (rc != 0) throw std::runtime_error("irf_create failed (no HIP device?)");
+        // BAM2blocks hands over fragments in the order of upstream's input: collated by read name, scattered over the
+        // genome.  The engine bins every batch by coordinate first (reorder.hip) unless the caller knows better.
+        if (irf_set_input_order(ctx_, input_order) != 0) {
+            const std::string msg = std::string("irf_set_input_order: ") + irf_last_error(ctx_);
+            irf_destroy(ctx_);
+            throw std::runtime_error(msg);
+        }
         cap_frag_ = batch_fragments;
         cap_blk_ = (uint64_t)batch_fragments * blocks_per_fragment_hint;
         for (int s = 0; s < 2; s++) alloc_slot(slot_[s]);

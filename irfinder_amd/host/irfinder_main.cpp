@@ -181,7 +181,8 @@ int main(int argc, char** argv) {
     bool mapped = false;
     try {
         if (via_adapter) {
-            adapter = new HipReadBlockProcessor(pos[1], pos[2], pos[3], pos[4], device, &P, (uint32_t)kBatchFrags);
+            adapter = new HipReadBlockProcessor(pos[1], pos[2], pos[3], pos[4], device, &P, (uint32_t)kBatchFrags, 6,
+                                                sorted_input ? IRF_ORDER_SORTED : IRF_ORDER_ANY);
             ctx = adapter->context();
         } else {
             char err[256] = {0};
@@ -190,6 +191,7 @@ int main(int argc, char** argv) {
             int rc = irf_create(&P, ref, device, &ctx);
             irf_ref_free(ref);
             if (rc != 0) return die("irf_create", "no HIP device or bad parameters");
+            if (!sorted_input && irf_set_input_order(ctx, IRF_ORDER_ANY) != 0) return die("irf_set_input_order", irf_last_error(ctx));
         }
         auto drain = [&](bool all) -> int {
             if (!mapped) {

@@ -184,7 +184,11 @@ def test_device_batch_with_malformed_csr_offsets_is_reported(order):
                        ("decreasing across groups", lambda a: a.__setitem__(1024, a[1023] - 1)),
                        ("beyond n_blk", lambda a: a.__setitem__(2000, batch.n_blk + 7)),
                        ("does not start at 0", lambda a: a.__setitem__(0, 1)),
-                       ("does not end at n_blk", lambda a: a.__setitem__(batch.n_frag, batch.n_blk - 1))):
+                       ("does not end at n_blk", lambda a: a.__setitem__(batch.n_frag, batch.n_blk - 1)),
+                       # every single range inside [0, n_blk] but their sum far beyond it (ORDER_ANY: the reordered blocks
+                       # must not be written past the arrays; the bounds were sized from n_blk)
+                       ("drops to 0 in the middle", lambda a: a.__setitem__(5, 0)),
+                       ("alternating 0 / n_blk", lambda a: a.__setitem__(slice(1, batch.n_frag, 2), batch.n_blk) or a.__setitem__(slice(2, batch.n_frag, 2), 0))):
         bad = good.copy()
         edit(bad)
         with pytest.raises(engine.IrfError) as ei:
@@ -429,6 +433,18 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     head, recs = _split_bam(bam)
     recs.sort(key=lambda r: struct.unpack_from("<ii", r, 4))
     (tmp_path / "sorted.bam").write_bytes(bgzf_compress(head + b"".join(recs)))
+    # the collated records with their read groups (mates adjacent) in a random order: what BAM2blocks hands the adapter,
+    # whose engine bins every batch by coordinate itself (HipReadBlockProcessor sets IRF_ORDER_ANY)
+    _, recs = _split_bam(bam)
+    groups = []
+    for r in recs:
+        nm = r[36:36 + r[12]]
+        if groups and groups[-1][0] == nm:
+            groups[-1][1].append(r)
+        else:
+            groups.append((nm, [r]))
+    order = np.random.default_rng(5).permutation(len(groups))
+    (tmp_path / "shuffled.bam.raw").write_bytes(head + b"".join(b"".join(groups[i][1]) for i in order))
     refs = [str(tmp_path / n) for n in names]
     cpu = tmp_path / "cpu"
     cpu.mkdir()
@@ -437,7 +453,8 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
     assert p.returncode == 0, p.stderr
     cpu_stdout = p.stdout
     exe = os.path.join(root, "irfinder_amd", "irfinder_hip")
-    for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("bgzf", ["--bgzf"], "in.bam"),
+    for tag, extra, src in (("direct", [], "in.bam.raw"), ("adapter", ["--via-adapter"], "in.bam.raw"), ("adapter-shuffled", ["--via-adapter"], "shuffled.bam.raw"),
+                            ("bgzf", ["--bgzf"], "in.bam"),
                             ("sorted", ["--bgzf", "--sorted", "--threads", "4"], "sorted.bam"),
                             ("device-reader", ["--device-reader"], "in.bam"), ("device-reader-1mb", ["--device-reader", "--feed-mb", "1"], "in.bam"),
                             ("device-reader-pipe", ["--device-reader"], "in.bam"),
@@ -525,6 +542,11 @@ def test_irf_gather_collects_shards_into_the_root_context(tmp_path):
         engs[root].write_outputs(str(out))
         for f in sorted(os.listdir(tmp_path / "whole")):
             assert filecmp.cmp(out / f, tmp_path / "whole" / f, shallow=False), f
+        # a second gather of the same sample would add the peers' columns twice: refused, the results stay as they are
+        with pytest.raises(engine.IrfError) as ei2:
+            engine.gather(engs, root=root)
+        assert ei2.value.code == -4
+        assert_results_equal(engs[root].results(), whole, rel=0.0, what="after the refused second gather")
     # the pieces of the recipe for one process per GPU: export (masked rows) -> add -> import, junction rows as coordinates
     import torch
     from irfinder_amd._abi import COL_IR_NONDIR_F64, COL_KEEP_ORPHANS
