@@ -172,10 +172,24 @@ def main():
     phase = {"reset+submit": 0.0, "finalize": 0.0, "export+gather": 0.0, "d2h": 0.0}
     step_log = []
 
-    def step():
+    kt = {"count_ms": 0.0, "scan_ms": 0.0, "stats_ms": 0.0, "junction_ms": 0.0}
+    kt_n = [0]
+
+    def take_timing():
+        # HIP-event times of the sample finalized last (irf_get_timing); read after the NEXT sample was submitted, when the
+        # library has waited for that sample anyway (irf_reset), so that the loop adds no wait of its own
+        tm = eng.timing()
+        for k in kt:
+            kt[k] += tm[k]
+        kt_n[0] += 1
+        return tm
+
+    def step(first=False):
         t_a = time.perf_counter()
         eng.reset()
         eng.submit(dbatch)
+        if not first:
+            take_timing()
         t_b = time.perf_counter()
         eng.finalize()
         t_c = time.perf_counter()
@@ -272,17 +286,17 @@ def main():
     barrier()
     for k in phase:
         phase[k] = 0.0
+    for k in kt:
+        kt[k] = 0.0
+    kt_n[0] = 0
     t0 = time.perf_counter()
-    kt = {"count_ms": 0.0, "scan_ms": 0.0, "stats_ms": 0.0, "junction_ms": 0.0}
-    tm = {}
-    for _ in range(args.steps):
-        step()
-        tm = eng.timing()
-        for k in kt:
-            kt[k] += tm[k]
+    for i in range(args.steps):
+        step(first=(i == 0))
     eng.sync()          # the last sample's tables are in host memory
     barrier()
     dt = time.perf_counter() - t0
+    tm = take_timing()
+    assert kt_n[0] == args.steps
     gc.enable()
     log("rank %d host ms per step (reset+submit, finalize, export): %s" % (rank, step_log[-args.steps:]))
     if world > 1:
@@ -318,7 +332,8 @@ def main():
     }
     dom = max(alg, key=lambda k: kt[k])
     achieved = alg[dom] / (kt[dom] * 1e-3) / 1e9 if kt[dom] > 0 else 0.0
-    kernels = {k: {"ms": round(kt[k], 4), "alg_bytes": int(alg[k]), "GBps": round(alg[k] / (kt[k] * 1e-3) / 1e9, 1) if kt[k] > 0 else None}
+    kernels = {k: {"ms": round(kt[k], 4), "alg_bytes": int(alg[k]), "GBps": round(alg[k] / (kt[k] * 1e-3) / 1e9, 1) if kt[k] > 0 else None,
+                   "frac": round(alg[k] / (kt[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kt[k] > 0 else None}
                for k in alg}
     # novel junctions: event buffer written by the count kernel (8 B), key-bits pass (read), per radix pass histogram read
     # + scatter read + write, head flags + compaction reads; known-junction lookups ride in the same interval
@@ -336,23 +351,33 @@ def main():
     knames = {"count_ms": ["count_kernel"], "scan_ms": ["scan_tiles_kernel", "reduce_tiles_kernel"],
               "stats_ms": ["intron_stats_kernel<256", "intron_stats_kernel<64"]}
     traffic_note = None
+    PMC_FILE = "r04_pmc_summary.json"        # round 3's counters (profiles/README.md: files are named rNN = BENCH round + 1)
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         if world == 1 and args.genome == "grch38" and args.pairs == 50_000_000 and not args.stranded and args.order == "sorted":
             # the counters were collected on a particular version of the kernels: a later change of their sources makes the
             # committed figure stale, and the line then says so instead of repeating it
             import hashlib
             cur = {f: hashlib.sha256(open(os.path.join(ROOT, "irfinder_amd", "csrc", f), "rb").read()).hexdigest()[:16] for f in ("count.hip", "stats.hip", "kernels.h")}
             if pmc.get("sources_sha256") == cur:
-                traffic = sum(pmc["kernels"][k]["hbm_bytes_corrected"] for k in knames[dom])
-                traffic_note = "profiles/r03_pmc_summary.json (tools/pmc_traffic.sh on these kernel sources)"
+                # (a kernel's instantiations are separate entries, keyed with their template arguments: the statistics
+                #  launch whose shape does not fit the strandedness vote returns at once and adds next to nothing)
+                def traffic_of(prefixes):
+                    return sum(v["hbm_bytes_corrected"] for n, v in pmc["kernels"].items() if any(n.startswith(q) for q in prefixes))
+                traffic = traffic_of(knames[dom])
+                traffic_note = "profiles/%s (tools/pmc_traffic.sh on these kernel sources)" % PMC_FILE
+                for k in knames:
+                    t_k = traffic_of(knames[k])
+                    kernels[k]["traffic"] = int(t_k)
+                    kernels[k]["wasted"] = round(t_k / alg[k], 3) if alg[k] else None
             else:
-                traffic_note = "profiles/r03_pmc_summary.json was collected on other kernel sources: run tools/pmc_traffic.sh again"
+                traffic_note = "profiles/%s was collected on other kernel sources: run tools/pmc_traffic.sh again" % PMC_FILE
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "kernel": {"count_ms": "count_kernel", "scan_ms": "scan_tiles_kernel", "stats_ms": "intron_stats_kernel"}[dom],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_note, "per_kernel": kernels, "layout": lay}
+                "traffic": traffic, "wasted": round(traffic / alg[dom], 3) if traffic else None,
+                "traffic_source": traffic_note, "per_kernel": kernels, "layout": lay}
 
     # ---------------- CPU baseline (oracle, bounded sample, 1 core) ----------------
     cpu = None

@@ -210,7 +210,15 @@ int irf_wait(irf_ctx* ctx, uint64_t batch_id);
 /* End of input: scan depth, per-intron statistics, junction sort-reduce,
  * directionality vote, IR tables.  Results stay on the device until
  * irf_get_results.  Replaces the end-of-run half of ⟨upstream⟩ irfinder.cpp
- * main() up to (not including) the file writers.                             */
+ * main() up to (not including) the file writers.
+ * Returns when the input errors of the sample are known (it waits for the count
+ * kernels) and all of its own work is QUEUED on the context's stream; it does not
+ * wait for the statistics kernels.  Every call that reads a result waits first
+ * (irf_get_results, irf_write_outputs, irf_get_depth, irf_get_timing, an
+ * irf_export_device without IRF_COL_NO_SYNC, irf_finalize_directional), and so do
+ * irf_sync and irf_reset; exports with IRF_COL_NO_SYNC queue behind it.  A caller
+ * that counts sample after sample can thus prepare the next submission while this
+ * sample's statistics kernels still run.                                        */
 int irf_finalize(irf_ctx* ctx);
 /* Multi-GPU (no upstream counterpart; upstream is one process): JunctionCount::Directional() is a vote over ALL
  * known junctions, so with chromosome shards the votes {same, opposite} of every rank are summed by the host
@@ -332,6 +340,8 @@ typedef struct irf_timing {
     uint64_t n_sort_records;   /* (key, weight) records the novel-junction radix sort-reduce ran over (the count kernel
                                   merges a chunk's events on one junction before it appends them)                        */
 } irf_timing;
+/* Kernel times of the last finalized sample (waits for it).  Between irf_reset and the next irf_finalize: of the
+ * sample before the reset, so that a loop over samples can read them without an extra wait of its own.            */
 int irf_get_timing(irf_ctx* ctx, irf_timing* out);
 
 /* Page-locked host memory for batch arrays (async H2D copies need it).  No

@@ -83,16 +83,31 @@ struct irf_ctx {
     hipStream_t export_stream = nullptr;
     hipEvent_t ev_tables_ready = nullptr, ev_export_done = nullptr;
     bool exports_pending = false;
+    // IR-table exports that were only queued (IRF_COL_NO_SYNC) are HELD BACK until the next sample's count kernel has been
+    // launched (or until anything waits for them or writes the tables): while a device-to-host copy kernel is in flight, no
+    // other kernel completes before it does (seen in the kernel trace), so copies issued right away stood between the
+    // small kernels in front of the next count kernel and cost the step their whole duration.
+    struct HeldExport { void* dst; const void* src; size_t bytes; };
+    std::vector<HeldExport> held_exports;
+    int flush_exports() {
+        if (held_exports.empty()) return 0;
+        HIP_TRY(hipStreamWaitEvent(export_stream, ev_tables_ready, 0));
+        for (const HeldExport& h : held_exports) HIP_TRY(hipMemcpyAsync(h.dst, h.src, h.bytes, hipMemcpyDefault, export_stream));
+        HIP_TRY(hipEventRecord(ev_export_done, export_stream));
+        held_exports.clear();
+        return 0;
+    }
     int order_after_exports() {
+        if (int rc = flush_exports()) return rc;
         if (exports_pending) { HIP_TRY(hipStreamWaitEvent(stream, ev_export_done, 0)); exports_pending = false; }
         return 0;
     }
     hipStream_t junc_stream = nullptr;           // the novel-junction sort of irf_finalize, next to the statistics kernels
-    hipEvent_t ev_junc_done = nullptr;
     hipEvent_t ev_scalars = nullptr;             // irf_finalize: the scalars and error flags have reached h_scal
     unsigned long long* h_scal = nullptr;        // page-locked: d_scalars[0..8), then the error flags
     std::string err;
     bool have_map = false, finalized = false, results_ready = false;
+    bool final_pending = false;                  // irf_finalize has queued its work; nobody has waited for it yet (settle())
     bool gathered = false;                       // irf_gather added the peers' columns to this context's (once per sample)
     bool kj_depth_applied = false;               // the known-junction difference events of this sample are in the planes (finalize may be called again after a failure)
 
@@ -212,10 +227,19 @@ struct irf_ctx {
     int32_t directionality = 0;
 
     // ---- timing ----
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> count_events;
-    size_t count_events_used = 0;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    irf_timing timing;
+    // Timing events of a sample.  Two sets, used alternately (irf_reset switches): the events of the sample that just ended
+    // stay readable while the next sample records its own, so that irf_get_timing can work the times out (a dozen
+    // hipEventElapsedTime calls: not free) when it is asked, not between two samples while the device waits.
+    struct EvSet {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> count_events;
+        size_t count_events_used = 0;
+        hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t junc_done = nullptr;
+        bool finalized = false, timed = false;   // irf_finalize recorded its events / `timing` holds the times read off them
+        irf_timing timing;
+    } evset[2];
+    int cur_set = 0;
+    void collect_timing(EvSet& E);
 
     // ---- host results ----
     std::vector<uint64_t> h_chr_cnt, h_roi_cnt;
@@ -240,6 +264,7 @@ struct irf_ctx {
     dev::IntronTables intron_tables(int t, int dirn, bool dual);
     int finalize();
     int finalize_directional(int32_t dirn);
+    int settle();
     int fetch_results();
     int export_col(uint32_t what, void* dst, uint64_t* n_out);
     int import_col(uint32_t what, const void* src, uint64_t n);
@@ -298,11 +323,14 @@ int irf_ctx::init() {
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_TRY(hipStreamCreateWithPriority(&junc_stream, hipStreamNonBlocking, greatest));
         HIP_TRY(hipStreamCreateWithPriority(&clear_stream, hipStreamNonBlocking, least));      // (yields to the export's copy kernels)
-        HIP_TRY(hipEventCreate(&ev_junc_done));
+        for (auto& E : evset) HIP_TRY(hipEventCreate(&E.junc_done));
         HIP_TRY(hipEventCreateWithFlags(&ev_scalars, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void**)&h_scal, 16 * sizeof(unsigned long long), hipHostMallocDefault));
         memset(h_scal, 0, 16 * sizeof(unsigned long long));
-        HIP_TRY(hipStreamCreateWithFlags(&export_stream, hipStreamNonBlocking));
+        // The queued exports of the IR tables use the junction stream: it is idle from the end of one sample's sort to the
+        // next sample's, and a fifth stream would share a hardware queue with one of the others (four per process: the
+        // copies then hold back the next sample's count kernel, seen in the kernel trace).
+        export_stream = junc_stream;
         HIP_TRY(hipEventCreateWithFlags(&ev_tables_ready, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_export_done, hipEventDisableTiming));
     }
@@ -312,8 +340,10 @@ int irf_ctx::init() {
         HIP_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
     }
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-    memset(&timing, 0, sizeof timing);
+    for (auto& E : evset) {
+        for (auto& e : E.ev) HIP_TRY(hipEventCreate(&e));
+        memset(&E.timing, 0, sizeof E.timing);
+    }
     return 0;
 }
 
@@ -323,18 +353,20 @@ void irf_ctx::free_events() {
         if (s.consumed) (void)hipEventDestroy(s.consumed);
         s.copied = s.consumed = nullptr;
     }
-    for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    for (auto& p : count_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    count_events.clear();
+    for (auto& E : evset) {
+        for (auto& e : E.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto& p : E.count_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        E.count_events.clear();
+        if (E.junc_done) { (void)hipEventDestroy(E.junc_done); E.junc_done = nullptr; }
+    }
     if (ev_stats_done) { (void)hipEventDestroy(ev_stats_done); ev_stats_done = nullptr; }
     for (auto& sp : spare) if (sp.cleared) { (void)hipEventDestroy(sp.cleared); sp.cleared = nullptr; }
     if (clear_stream) { (void)hipStreamDestroy(clear_stream); clear_stream = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
-    if (ev_junc_done) { (void)hipEventDestroy(ev_junc_done); ev_junc_done = nullptr; }
     if (ev_scalars) { (void)hipEventDestroy(ev_scalars); ev_scalars = nullptr; }
     if (h_scal) { (void)hipHostFree(h_scal); h_scal = nullptr; }
-    if (export_stream) { (void)hipStreamSynchronize(export_stream); (void)hipStreamDestroy(export_stream); export_stream = nullptr; }
+    export_stream = nullptr;         // (an alias of the junction stream)
     if (ev_tables_ready) { (void)hipEventDestroy(ev_tables_ready); ev_tables_ready = nullptr; }
     if (ev_export_done) { (void)hipEventDestroy(ev_export_done); ev_export_done = nullptr; }
     if (junc_stream) { (void)hipStreamDestroy(junc_stream); junc_stream = nullptr; }
@@ -346,7 +378,9 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipStreamSynchronize(copy_stream));
+    TRY(settle());
     // exports of the last sample may still be reading the tables that are reallocated below
+    TRY(flush_exports());
     if (export_stream) HIP_TRY(hipStreamSynchronize(export_stream));
     exports_pending = false;
     n_chr = n;
@@ -730,6 +764,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
 
 int irf_ctx::zero_counters() {
     HIP_TRY(hipSetDevice(device));
+    TRY(settle());                   // (the events of the sample that ends here are recorded again below)
     // (a spare set of planes, cleared behind an earlier sample's statistics kernels, is swapped in; without one the planes
     //  are cleared in line)
     PlaneSet* take = nullptr;        // the spare set whose clear was queued first
@@ -755,8 +790,11 @@ int irf_ctx::zero_counters() {
     ir_prepared[0] = ir_prepared[1] = false;
     imp_junc.clear();
     directionality = 0;
-    count_events_used = 0;
-    memset(&timing, 0, sizeof timing);
+    cur_set ^= 1;                    // (the other set's events are those of the sample before the last: long complete)
+    EvSet& E = evset[cur_set];
+    E.count_events_used = 0;
+    E.finalized = E.timed = false;
+    memset(&E.timing, 0, sizeof E.timing);
     return 0;
 }
 
@@ -885,17 +923,19 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
             if (d_chunk_origin.reserve(need + need / 4) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the chunk table failed");
         }
     }
-    if (count_events_used == count_events.size()) {
+    EvSet& E = evset[cur_set];
+    if (E.count_events_used == E.count_events.size()) {
         hipEvent_t a, z;
         HIP_TRY(hipEventCreate(&a));
         HIP_TRY(hipEventCreate(&z));
-        count_events.emplace_back(a, z);
+        E.count_events.emplace_back(a, z);
     }
-    auto& evp = count_events[count_events_used++];
+    auto& evp = E.count_events[E.count_events_used++];
     HIP_TRY(hipEventRecord(evp.first, stream));
     dev::launch_count(count_tables(), d_ctab.p, &ctab_shadow, B, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(evp.second, stream));
+    TRY(flush_exports());            // (the last sample's held-back table copies run under this count kernel)
     if (st) HIP_TRY(hipEventRecord(st->consumed, stream));
     n_fragments += b->n_frag;
     n_blocks += b->n_blk;
@@ -978,6 +1018,8 @@ int irf_ctx::finalize() {
     if (!have_map) return fail(IRF_E_STATE, "irf_finalize before irf_chr_map_update");
     if (finalized) return 0;
     HIP_TRY(hipSetDevice(device));
+    EvSet& E = evset[cur_set];
+    hipEvent_t* const ev = E.ev;
     HIP_TRY(hipStreamSynchronize(copy_stream));
     HIP_TRY(hipEventRecord(ev[0], stream));
     // Everything that needs no answer from the device is queued before the first synchronisation: the depth carries
@@ -1103,10 +1145,10 @@ int irf_ctx::finalize() {
         dev::launch_junction_lookups(J, stream);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(ev_junc_done, stream));
+    HIP_TRY(hipEventRecord(E.junc_done, stream));
     }
     // ---- the junction-dependent columns of the rows ----
-    HIP_TRY(hipStreamWaitEvent(stream, ev_junc_done, 0));
+    HIP_TRY(hipStreamWaitEvent(stream, E.junc_done, 0));
     HIP_TRY(hipEventRecord(ev[2], stream));
     if (directionality != 0) dev::launch_ir_rows(intron_tables(0, directionality, true), stream);
     else dev::launch_ir_rows(intron_tables(0, 0, false), stream);
@@ -1155,28 +1197,51 @@ int irf_ctx::finalize() {
             sp.seq = ++clear_seq;
         }
     }
+    // Everything is queued.  The host does not wait for it here: whatever reads a result (irf_get_results, an export that
+    // is not IRF_COL_NO_SYNC, irf_get_timing, irf_get_depth), irf_reset and irf_sync wait first (settle()), and exports with
+    // IRF_COL_NO_SYNC queue behind it.  A caller that counts sample after sample thus prepares the next sample's
+    // submission while the statistics kernels of this one still run.
+    E.timing.n_count_launches = (uint32_t)E.count_events_used;
+    E.timing.n_radix_passes = n_radix_passes;
+    E.timing.n_sort_records = n_events;
+    E.finalized = true;
+    E.timed = false;
+    finalized = true;
+    final_pending = true;
+    gathered = false;
+    results_ready = false;
+    return 0;
+}
+
+// Waits for what irf_finalize queued.
+int irf_ctx::settle() {
+    if (!final_pending) return 0;
+    HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize(stream));
-    // ---- timing ----
+    final_pending = false;
+    return 0;
+}
+
+// The kernel times of a finalized sample, read off its events (which are complete: settle() ran).
+void irf_ctx::collect_timing(EvSet& E) {
+    if (E.timed || !E.finalized) return;
+    irf_timing& timing = E.timing;
+    hipEvent_t* const ev = E.ev;
     float ms = 0;
     timing.count_ms = 0;
-    for (size_t i = 0; i < count_events_used; i++) {
-        if (hipEventElapsedTime(&ms, count_events[i].first, count_events[i].second) == hipSuccess) timing.count_ms += ms;
+    for (size_t i = 0; i < E.count_events_used; i++) {
+        if (hipEventElapsedTime(&ms, E.count_events[i].first, E.count_events[i].second) == hipSuccess) timing.count_ms += ms;
     }
-    timing.n_count_launches = (uint32_t)count_events_used;
-    timing.n_radix_passes = n_radix_passes;
-    timing.n_sort_records = n_events;
     if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) timing.scan_ms = ms;
     // (junction_ms: known-junction lookups and the vote, up to the start of the statistics kernels, + the sort-reduce of the
     //  novel junctions, which runs NEXT TO the statistics kernels: the two overlap, their sum is not a wall time)
     if (hipEventElapsedTime(&ms, ev[1], ev[4]) == hipSuccess) timing.junction_ms = ms;
-    if (hipEventElapsedTime(&ms, ev[4], ev_junc_done) == hipSuccess) timing.junction_ms += ms;
+    if (hipEventElapsedTime(&ms, ev[4], E.junc_done) == hipSuccess) timing.junction_ms += ms;
     if (hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) timing.stats_ms = ms;
     if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) timing.table_ms = ms;       // launch_ir_rows
     if (hipEventElapsedTime(&ms, ev[0], ev[3]) == hipSuccess) timing.total_finalize_ms = ms;
-    finalized = true;
-    gathered = false;
-    results_ready = false;
-    return 0;
+    (void)hipGetLastError();
+    E.timed = true;
 }
 
 // Multi-GPU: the strandedness vote must be taken over ALL shards.  The host sums irf_get_votes over the ranks,
@@ -1184,6 +1249,7 @@ int irf_ctx::finalize() {
 int irf_ctx::finalize_directional(int32_t dirn) {
     if (!finalized) return fail(IRF_E_STATE, "irf_finalize_directional before irf_finalize");
     dirn = dirn > 0 ? 1 : (dirn < 0 ? -1 : 0);
+    TRY(settle());
     if (dirn == directionality) return 0;
     HIP_TRY(hipSetDevice(device));
     directionality = dirn;
@@ -1204,6 +1270,7 @@ int irf_ctx::fetch_results() {
     if (!finalized) return fail(IRF_E_STATE, "results requested before irf_finalize");
     if (results_ready) return 0;
     HIP_TRY(hipSetDevice(device));
+    TRY(settle());
     std::vector<uint32_t> tmp;
     auto down32 = [&](const uint32_t* p, size_t n) -> hipError_t {
         tmp.resize(n);
@@ -1326,9 +1393,7 @@ int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
     if (table >= 0 && !sharded && no_sync) {
         // an IR table, copy only queued: on the export stream, behind everything queued on the main stream so far
         HIP_TRY(hipEventRecord(ev_tables_ready, stream));
-        HIP_TRY(hipStreamWaitEvent(export_stream, ev_tables_ready, 0));
-        HIP_TRY(hipMemcpyAsync(dst, src, n * elem, hipMemcpyDefault, export_stream));
-        HIP_TRY(hipEventRecord(ev_export_done, export_stream));
+        held_exports.push_back(HeldExport{dst, src, (size_t)(n * elem)});       // (issued by flush_exports)
         exports_pending = true;
         return 0;
     }
@@ -1339,7 +1404,7 @@ int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
         else dev::launch_mask_rows_u32((uint32_t*)dst, 6, n_intron, d_row_code.p, keep, stream);
         HIP_TRY(hipGetLastError());
     }
-    if (!no_sync) HIP_TRY(hipStreamSynchronize(stream));
+    if (!no_sync) { HIP_TRY(hipStreamSynchronize(stream)); TRY(settle()); }
     return 0;
 }
 
@@ -1368,6 +1433,7 @@ int irf_ctx::import_col(uint32_t what, const void* src, uint64_t n) {
     }
     if (n != want) return fail(IRF_E_ARG, "irf_import_device: element count does not match this context's table");
     if (!n) return 0;
+    TRY(settle());
     TRY(order_after_exports());
     if (table >= 0 && !ir_prepared[table]) {
         const uint32_t keep = (1u << dev::kRowMine) | (1u << dev::kRowOrphan);
@@ -1389,6 +1455,7 @@ int irf_ctx::own_novel_junctions(std::vector<ImpJunc>& out) {
     out.clear();
     if (!n_unique) return 0;
     HIP_TRY(hipSetDevice(device));
+    TRY(settle());
     std::vector<uint64_t> uk(n_unique);
     std::vector<uint32_t> uc(n_unique);
     HIP_TRY(hipMemcpy(uk.data(), d_ukeys.p, n_unique * 8, hipMemcpyDeviceToHost));
@@ -1500,6 +1567,7 @@ void irf_destroy(irf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->clear_stream) (void)hipStreamSynchronize(c->clear_stream);
+    if (c->junc_stream) (void)hipStreamSynchronize(c->junc_stream);      // (table exports in flight)
     c->free_events();
     delete c;
 }
@@ -1520,10 +1588,12 @@ int irf_submit_batch(irf_ctx* c, const irf_batch* b, uint64_t* id) { return c ? 
 int irf_wait(irf_ctx* c, uint64_t id) { return c ? c->wait(id) : IRF_E_ARG; }
 int irf_sync(irf_ctx* c) {
     if (!c) return IRF_E_ARG;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+    if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
+    if (int rc = c->flush_exports()) return rc;
+    if (hipStreamSynchronize(c->stream) != hipSuccess ||
         (c->export_stream && hipStreamSynchronize(c->export_stream) != hipSuccess)) return c->fail(IRF_E_DEVICE, "irf_sync: stream synchronize failed");
     c->exports_pending = false;
-    return 0;
+    return c->settle();
 }
 int irf_set_input_order(irf_ctx* c, uint32_t order) {
     if (!c) return IRF_E_ARG;
@@ -1588,6 +1658,7 @@ int irf_get_depth(irf_ctx* c, uint32_t chr, uint32_t start, uint32_t end, uint32
     if (!c->pmap.empty()) return c->fail(IRF_E_STATE, "irf_get_depth needs params.keep_depth = 1 (the default keeps only the measured intron regions in HBM)");
     if (chr >= c->n_chr || !c->chr_owned[chr] || start > end || end > c->chr_len[chr] || dir > 2) return c->fail(IRF_E_ARG, "irf_get_depth: bad range");
     if (hipSetDevice(c->device) != hipSuccess) return c->fail(IRF_E_DEVICE, "hipSetDevice");
+    if (int rc = c->settle()) return rc;
     size_t n = end - start;
     if (!n) return 0;
     // depth = carry of the enclosing 256-position segment + running sum of the difference events (host side)
@@ -1720,7 +1791,10 @@ int irf_get_layout(irf_ctx* c, irf_layout* out) {
 
 int irf_get_timing(irf_ctx* c, irf_timing* out) {
     if (!c || !out) return IRF_E_ARG;
-    *out = c->timing;
+    if (int rc = c->settle()) return rc;
+    irf_ctx::EvSet& E = c->evset[c->finalized ? c->cur_set : c->cur_set ^ 1];      // (after irf_reset: the sample before it)
+    c->collect_timing(E);
+    *out = E.timing;
     return 0;
 }
 

@@ -565,8 +565,10 @@ def test_irf_gather_collects_shards_into_the_root_context(tmp_path):
         b.import_device(COL_IR_NONDIR_F64, t.data_ptr(), n - 1)          # wrong element count
 
 
-def test_chr22_scale_matches_oracle_and_properties():
-    """BASELINE configs[0] shape (2 M simulated 2x100 pairs, chr22-sized reference, unstranded) — the largest size the
+@pytest.mark.parametrize("stranded", [False, True])
+def test_chr22_scale_matches_oracle_and_properties(stranded):
+    """BASELINE configs[0] shape (2 M simulated 2x100 pairs, chr22-sized reference; unstranded as the config says, and a
+    stranded twin so that the one-pass two-table statistics are oracle-checked at this size) — the largest size the
     oracle finishes in seconds — bit-exact, plus the size-independent properties used at the full bench size:
     P4 nondir = pos + neg (via the directional planes of a stranded twin), P5 sum of FragmentsInChr = fragments,
     P6 SpliceLeft/Right are sums of junction rows."""
@@ -574,12 +576,13 @@ def test_chr22_scale_matches_oracle_and_properties():
     from irfinder_amd.synth.annotation import GRCH38, make_annotation
     from irfinder_amd.synth.reads import ReadSimulator
     ann = make_annotation([GRCH38[21]], seed=20240807)
-    sim = ReadSimulator(ann, read_len=100, seed=20240807)
+    sim = ReadSimulator(ann, read_len=100, seed=20240807, stranded=stranded)
     batches, st = synth_world.generate_batches(sim, 0, 2_000_000, chunk=250_000, threads=8)
     whole = synth_world.sort_by_coordinate(synth_world.concat_batches(batches))
     e, g = run_gpu(ann.ref_texts(), ann.chr_names, ann.chr_lens, [whole])
     o, c = run_orc(ann.ref_texts(), ann.chr_names, ann.chr_lens, batches)          # oracle sees the unsorted chunks
-    assert_results_equal(g, c, rel=0.0, what="chr22 2M pairs")
+    assert_results_equal(g, c, rel=0.0, what="chr22 2M pairs, stranded=%s" % stranded)
+    assert bool(g["has_dir"]) == stranded
     assert g["chr_cnt"].sum() == whole.n_frag == st["n_pairs"] + st["n_singles"]
     # P6 on the device result: SpliceLeft of an intron = sum over junction rows sharing its start
     starts = np.array([int(l.split("\t")[1]) for l in ann.cover_bed.splitlines()])
@@ -589,6 +592,32 @@ def test_chr22_scale_matches_oracle_and_properties():
         left_sum[int(l)] = left_sum.get(int(l), 0) + int(t)
     exp = np.array([left_sum.get(int(s), 0) for s in starts])
     assert np.array_equal(exp, g["nondir"]["splice_left"])
+
+
+def test_grch38_sized_stranded_sample_matches_oracle():
+    """The GRCh38-sized reference of configs[1] / [2] (3.1 G positions, ~200 k introns, compact planes) with a STRANDED
+    4 M-pair sample: both IR tables (the one-pass two-table statistics kernel), the vote, every counter and the junction
+    table against the oracle, bit for bit.  (The 50 M-pair sizes are property-checked below; the oracle would need
+    minutes for them.)"""
+    from irfinder_amd.synth import world as synth_world
+    from irfinder_amd.synth.annotation import GRCH38, make_annotation
+    from irfinder_amd.synth.reads import ReadSimulator
+    ann = make_annotation(GRCH38, seed=20240808)
+    sim = ReadSimulator(ann, read_len=150, seed=20240808 + 2000, stranded=True)
+    batches, st = synth_world.generate_batches(sim, 0, 4_000_000, chunk=500_000, threads=16)
+    whole = synth_world.sort_by_coordinate(synth_world.concat_batches(batches))
+    e, g = run_gpu(ann.ref_texts(), ann.chr_names, ann.chr_lens, [whole])
+    o, c = run_orc(ann.ref_texts(), ann.chr_names, ann.chr_lens, batches)
+    assert g["has_dir"] and c["has_dir"]
+    assert_results_equal(g, c, rel=0.0, what="GRCh38-sized reference, 4M stranded pairs")
+    # the same sample in collated order through the binning step
+    e2 = engine.Engine(engine.RefTables.from_texts(ann.ref_texts()))
+    e2.chr_map_update(ann.chr_names, ann.chr_lens)
+    e2.set_input_order(1)
+    for b in batches:
+        e2.process(b)
+    e2.finalize()
+    assert_results_equal(e2.results(), c, rel=0.0, what="GRCh38-sized reference, 4M stranded pairs, IRF_ORDER_ANY")
 
 
 def test_full_size_properties_configs1():

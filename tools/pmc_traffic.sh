@@ -13,7 +13,7 @@ vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        m = re.search(r'(\w+_kernel(?:<\d+)?|fillBufferAligned|copyBuffer)', name)
+        m = re.search(r'(\w+_kernel(?:<[\d, ]+>)?|fillBufferAligned|copyBuffer)', name)
         key = m.group(1) if m else name[:40]
         vals[key][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --no-decode-bench --no-random-leg (two separate passes)",
