@@ -172,6 +172,7 @@ struct irf_ctx {
     DevBuf<uint4> d_jhash;                       // kernels.h: CountTables::jhash
     DevBuf<unsigned long long> d_chunk_origin;   // kernels.h: CountTables::chunk_origin (sized to the largest batch so far)
     DevBuf<dev::CountTables> d_ctab;             // the count kernel's table block (kernels.h: launch_count) ...
+    DevBuf<dev::IntronTables> d_itab;            // the statistics kernels' table blocks: [0] one table, [1] both (irf_finalize queues both shapes), [2] irf_finalize_directional
     dev::CountTables ctab_shadow;                // ... and what it holds
     uint32_t jh_mask = 0;
     DevBuf<uint64_t> d_junc_a, d_junc_b;          // novel-junction records: packed keys (+ sort buffer)
@@ -756,7 +757,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         if (e == hipSuccess) e = d_juncw_a.reserve(d_junc_a.cap);
         if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the junction event buffer failed");
     }
-    if (d_ctab.reserve(1) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the table block failed");
+    if (d_ctab.reserve(1) != hipSuccess || d_itab.reserve(3) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the table block failed");
     memset(&ctab_shadow, 0xff, sizeof ctab_shadow);          // (nothing uploaded yet)
     have_map = true;
     return zero_counters();
@@ -1011,7 +1012,7 @@ dev::IntronTables irf_ctx::intron_tables(int t, int dirn, bool dual) {
 }
 
 void irf_ctx::launch_stats(int t, int dirn, bool dual) {
-    dev::launch_intron_stats(intron_tables(t, dirn, dual), stats_classes, stream);
+    dev::launch_intron_stats(intron_tables(t, dirn, dual), d_itab.p + 2, stats_classes, stream);
 }
 
 int irf_ctx::finalize() {
@@ -1052,8 +1053,8 @@ int irf_ctx::finalize() {
         dev::IntronTables one = intron_tables(0, 0, false), two = intron_tables(0, 1, true);
         one.vote = two.vote = d_scalars.p + 3;
         one.dir_ratio = two.dir_ratio = P.dir_ratio;
-        dev::launch_intron_stats(one, stats_classes, stream);
-        dev::launch_intron_stats(two, stats_classes, stream);
+        dev::launch_intron_stats(one, d_itab.p + 0, stats_classes, stream);
+        dev::launch_intron_stats(two, d_itab.p + 1, stats_classes, stream);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[5], stream));

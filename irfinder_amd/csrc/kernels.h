@@ -313,7 +313,10 @@ struct IntronTables {
     uint32_t* out_u32_b;
     uint32_t* err_flags;
 };
-void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s);
+// d_T: device memory for one IntronTables (the kernels read their table block through it: as a by-value argument its
+// ~60 dwords stayed live in scalar registers through the whole kernel, 140-240 of them spilled into vector lanes); the block
+// is stored there by a one-thread kernel in front of the launch, in stream order
+void launch_intron_stats(const IntronTables& T, IntronTables* d_T, const StatsClasses& K, hipStream_t s);
 // The junction-dependent columns of the rows (SpliceLeft / SpliceRight / SpliceExact, IRratio, the warning) once more,
 // from the depth columns launch_intron_stats has written: irf_finalize starts the statistics kernels before the
 // novel-junction table is finished (T.n_unique = 0 there) and runs this afterwards with the finished tables.

@@ -63,6 +63,7 @@ namespace {
 #define STATS_MIN_WAVES_DUAL 6      // (4 = 128 registers, no spills: measured slower, 3.37 vs 3.17 ms on configs[2])
 #endif
 constexpr int kQueries = 8;
+constexpr uint32_t kFastBins = 256; // one-wave class: depths below this take the four-bins-per-lane rank queries
 constexpr int kSeg = 256;           // positions per carry segment (kernels.h: kDepthSegment)
 constexpr uint32_t kMaxBlk = 64;    // measured blocks per descriptor chunk: one per lane
 
@@ -75,11 +76,26 @@ __device__ uint32_t g_prof[kProfMax][8];
 #define PROF_MARK(k) do { } while (0)
 #endif
 
+// pointers that come out of the table block in device memory are generic to the compiler: cast to the global address
+// space, their loads stay global_load (a flat_load also counts against the LDS counter and waits with it)
+#define AS1 __attribute__((address_space(1)))
+template <class X> __device__ __forceinline__ AS1 X* gp(X* p) { return (AS1 X*)p; }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 load_int4(const AS1 int32_t* p) {
+    const i32x4 v = *reinterpret_cast<const AS1 i32x4*>(p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ BlkRec load_blk(const AS1 BlkRec* p) {
+    BlkRec r;
+    r.gstart = p->gstart; r.cstart = p->cstart; r.len = p->len; r.pad = 0;
+    return r;
+}
+
 struct Ctx {
-    const int32_t* d0;              // difference planes
-    const int32_t* d1;
-    const uint32_t* c0;             // carries, one per 256-position segment
-    const uint32_t* c1;
+    const AS1 int32_t* d0;          // difference planes
+    const AS1 int32_t* d1;
+    const AS1 uint32_t* c0;         // carries, one per 256-position segment
+    const AS1 uint32_t* c1;
     int plane;                      // 0,1: one strand; 2: both
 };
 
@@ -148,15 +164,15 @@ __device__ __forceinline__ Seg load_seg(const Ctx& C, uint64_t k, uint32_t lane)
     Seg s;
     const uint64_t e0 = k * kSeg + lane * 4u;
     if (C.plane == 2) {
-        const int4 u = *reinterpret_cast<const int4*>(C.d0 + e0);
-        const int4 v = *reinterpret_cast<const int4*>(C.d1 + e0);
+        const int4 u = load_int4(C.d0 + e0);
+        const int4 v = load_int4(C.d1 + e0);
         s.a.x = u.x + v.x; s.a.y = u.y + v.y; s.a.z = u.z + v.z; s.a.w = u.w + v.w;
         s.carry = C.c0[k] + C.c1[k];
     } else if (C.plane == 1) {
-        s.a = *reinterpret_cast<const int4*>(C.d1 + e0);
+        s.a = load_int4(C.d1 + e0);
         s.carry = C.c1[k];
     } else {
-        s.a = *reinterpret_cast<const int4*>(C.d0 + e0);
+        s.a = load_int4(C.d0 + e0);
         s.carry = C.c0[k];
     }
     return s;
@@ -168,14 +184,14 @@ struct RawSeg { int4 u, v; uint32_t cu, cv; };
 __device__ __forceinline__ RawSeg issue_seg(const Ctx& C, uint64_t k, uint32_t lane) {
     RawSeg r;
     const uint64_t e0 = k * kSeg + lane * 4u;
-    const int32_t* pu = C.plane == 1 ? C.d1 : C.d0;
-    const uint32_t* cu = C.plane == 1 ? C.c1 : C.c0;
-    r.u = *reinterpret_cast<const int4*>(pu + e0);
+    const AS1 int32_t* pu = C.plane == 1 ? C.d1 : C.d0;
+    const AS1 uint32_t* cu = C.plane == 1 ? C.c1 : C.c0;
+    r.u = load_int4(pu + e0);
     r.cu = cu[k];
     r.v = make_int4(0, 0, 0, 0);
     r.cv = 0;
     if (C.plane == 2) {
-        r.v = *reinterpret_cast<const int4*>(C.d1 + e0);
+        r.v = load_int4(C.d1 + e0);
         r.cv = C.c1[k];
     }
     return r;
@@ -280,7 +296,8 @@ __device__ __forceinline__ double percentile_value(const PctRanks& q, uint32_t v
 // the first anyway; the second takes the intron's own strand out of the same registers): two histograms, two sets of
 // flank windows, then medians / rank queries / row once per table.  kTables = 1: one table, T.directionality selects it.
 template <int kThreads, int kMaxFlank, int kInFlight, int kBinBits, int kTables>
-__global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : STATS_MIN_WAVES)) void intron_stats_kernel(IntronTables T, const uint32_t* __restrict__ wg_off, uint32_t prof_slot) {
+__global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : STATS_MIN_WAVES)) void intron_stats_kernel(const IntronTables* __restrict__ Tp, const uint32_t* __restrict__ wg_off, uint32_t prof_slot) {
+    const IntronTables& T = *Tp;
     constexpr int kWaves = kThreads / 64;
     constexpr int kBins = 1 << kBinBits;                   // histogram bins per level of the rank select
     constexpr int kBinsPerThread = kBins / kThreads;
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     __shared__ uint32_t s_med[4];                          // per window: the two order statistics its median reads
     __shared__ uint32_t s_wc[kWaves];
     __shared__ unsigned long long s_ws[kWaves];
-    __shared__ uint32_t s_max, s_overflow[kTables], s_sel_bin, s_sel_cnt;
+    __shared__ uint32_t s_max, s_overflow[kTables], s_hi[kTables], s_sel_bin, s_sel_cnt;
     __shared__ unsigned long long s_total, s_nz, s_acc;
     __shared__ uint32_t s_qval[kQueries];
     __shared__ unsigned long long s_qsum[kQueries];
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     if (k_begin >= k_end) return;
     int dirn = T.directionality;
     if (T.vote) {       // the decision is taken here (kernels.h); only the launch whose shape fits it goes on
-        const unsigned long long same = T.vote[0], opp = T.vote[1];
+        const unsigned long long same = gp(T.vote)[0], opp = gp(T.vote)[1];
         dirn = same > opp * (unsigned long long)T.dir_ratio ? 1 : (opp > same * (unsigned long long)T.dir_ratio ? -1 : 0);
         if ((kTables == 2) != (dirn != 0)) return;
     }
@@ -310,10 +327,10 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     Ctx C;
-    C.d0 = T.diff;
-    C.d1 = T.diff + T.plane_stride;
-    C.c0 = T.carry;
-    C.c1 = T.carry + T.plane_stride / kSeg;
+    C.d0 = gp(T.diff);
+    C.d1 = gp(T.diff) + T.plane_stride;
+    C.c0 = gp(T.carry);
+    C.c1 = gp(T.carry) + T.plane_stride / kSeg;
     C.plane = 2;
 
     // ---- the header pipeline -------------------------------------------------------------------------------------
@@ -321,29 +338,33 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     // introns before it: the record two introns ahead, the block descriptors and the row's counters one ahead.
     // Vector loads on purpose (lane l holds dword l of the record; every wave keeps its own copy): they retire in
     // order under vmcnt, so waiting for plane data never waits for anything younger, and no LDS wait drains them.
-    const uint32_t* __restrict__ recw = reinterpret_cast<const uint32_t*>(T.recs);
+    const AS1 uint32_t* __restrict__ recw = reinterpret_cast<const AS1 uint32_t*>(gp(T.recs));
+    const AS1 BlkRec* __restrict__ blks = gp(T.blks);
     auto load_rec = [&](uint32_t k) -> uint32_t {
         const uint32_t kc = k < k_end ? k : k_end - 1u;
         return recw[(uint64_t)kc * (sizeof(IntronRec) / 4u) + (lane & 31u)];
     };
     auto load_hdr = [&](uint32_t rec, BlkRec& d, uint32_t& tc) {
         const uint32_t blk_off = lane_u32(rec, 6), n_blk = lane_u32(rec, 7), flags = lane_u32(rec, 14);
-        d = T.blks[blk_off + (lane < n_blk ? lane : 0u)];              // the table ends with one spare entry
+        d = load_blk(blks + blk_off + (lane < n_blk ? lane : 0u));                // the table ends with one spare entry
         tc = 0;
         // lanes 0..9: sp_cnt[sp_s], sp_cnt[sp_e], left_cnt[us], right_cnt[ue], known_cnt[kj], each for both strands
         const uint32_t which = lane >> 1, half = lane & 1u;
         int32_t ix = -1;
-        const uint32_t* base = T.sp_cnt;
+        const AS1 uint32_t* base = gp(T.sp_cnt);
         uint64_t n = T.n_sp;
         const int32_t sp_s = (int32_t)lane_u32(rec, 8), sp_e = (int32_t)lane_u32(rec, 9), us = (int32_t)lane_u32(rec, 10),
                       ue = (int32_t)lane_u32(rec, 11), kj = (int32_t)lane_u32(rec, 12);
         if (which == 0u) ix = sp_s;
         else if (which == 1u) ix = sp_e;
-        else if (which == 2u) { ix = us; base = T.left_cnt; n = T.n_ustart; }
-        else if (which == 3u) { ix = ue; base = T.right_cnt; n = T.n_uend; }
-        else if (which == 4u) { ix = kj; base = T.known_cnt; n = T.n_kj; }
+        else if (which == 2u) { ix = us; base = gp(T.left_cnt); n = T.n_ustart; }
+        else if (which == 3u) { ix = ue; base = gp(T.right_cnt); n = T.n_uend; }
+        else if (which == 4u) { ix = kj; base = gp(T.known_cnt); n = T.n_kj; }
         if ((flags & 1u) && !(T.ablate & 2u) && ix >= 0) tc = base[(uint64_t)half * n + (uint64_t)ix];
     };
+    // The histograms are zero between introns: the rank queries read every bin that holds anything, and whoever read a
+    // bin clears it (a zeroing pass per intron cost a tenth of the kernel).
+    for (int k = tid; k < kTables * kBins / 4; k += kThreads) reinterpret_cast<uint4*>(s_cnt)[k] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t recA = load_rec(k_begin), recB = load_rec(k_begin + 1u);
     BlkRec dA;
     uint32_t tcA;
@@ -381,8 +402,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
         w0[1] = gE - (fo + fl < ilen ? fo + fl : ilen);
     }
 
-    for (int k = tid; k < kTables * kBins / 4; k += kThreads) reinterpret_cast<uint4*>(s_cnt)[k] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < kTables) s_overflow[tid] = 0;
+    if (tid < kTables) { s_overflow[tid] = 0; s_hi[tid] = 0; }
     if (tid == 0) { s_max = 0; s_total = 0; s_nz = 0; s_acc = 0; }
     if (tid < 4) s_med[tid] = 0;
     if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
@@ -393,9 +413,9 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     // (total, non-zero count and maximum are read off the histogram afterwards)
     uint32_t nwin[2] = {0, 0};
     if (valid) {
-        bool ovf[kTables];
+        bool ovf[kTables], hib[kTables];       // a depth beyond the histogram / of kFastBins or more was seen
 #pragma unroll
-        for (int t = 0; t < kTables; t++) ovf[t] = false;
+        for (int t = 0; t < kTables; t++) { ovf[t] = false; hib[t] = false; }
         if (!T.flank_use_measured) {
             // raw-coordinate windows: the engine keeps the buckets under them, contiguous in the plane
             for (int wi = 0; wi < 2; wi++) {
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             const uint32_t nbc = nb - cb < kMaxBlk ? nb - cb : kMaxBlk;
             const bool has = lane < nbc;
             BlkRec br = dA;                                            // the first chunk came with the header
-            if (cb) br = T.blks[b0 + cb + (has ? lane : 0u)];
+            if (cb) br = load_blk(blks + b0 + cb + (has ? lane : 0u));
             const uint64_t d_bc = br.cstart;
             const uint32_t d_bl = has ? br.len : 0u;
             const uint32_t d_nseg = d_bl ? (uint32_t)((d_bc + d_bl - 1u) / kSeg - d_bc / kSeg + 1u) : 0u;
@@ -497,6 +517,8 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
                         const uint32_t incl = wave_inclusive_scan_dpp(tt);
                         const uint32_t v0 = sgj.carry + incl - tt + (uint32_t)sgj.a.x;
                         const uint32_t v1 = v0 + (uint32_t)sgj.a.y, v2 = v1 + (uint32_t)sgj.a.z, v3 = v2 + (uint32_t)sgj.a.w;
+                        // (conservative: positions outside the measured part count too; the flag only selects the query path)
+                        hib[t] = hib[t] || ((v0 | v1 | v2 | v3) >= kFastBins);
                         // Depth is piecewise constant.  A lane whose four positions are all measured and equal ("full") is
                         // one histogram entry of weight 4; full lanes are merged per value by the wave (two rounds of
                         // leader election: a segment rarely holds more than two frequent depths), the rest add on their own.
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             }
         }
 #pragma unroll
-        for (int t = 0; t < kTables; t++) if (ovf[t]) s_overflow[t] = 1;
+        for (int t = 0; t < kTables; t++) { if (ovf[t]) s_overflow[t] = 1; if (hib[t]) s_hi[t] = 1; }
         PROF_MARK(1);
     } else {
         // all-zero depth: N zeros in the histogram, all-zero windows of the right size
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             if (w0[wi] < w1[wi]) {
                 if (T.flank_use_measured) {
                     for (uint32_t b = b0; b < b0 + nb; b++) {
-                        const uint64_t bs = T.blks[b].gstart, be = bs + T.blks[b].len;
+                        const uint64_t bs = blks[b].gstart, be = bs + blks[b].len;
                         const uint64_t s = bs > w0[wi] ? bs : w0[wi], e = be < w1[wi] ? be : w1[wi];
                         if (s < e) n += (uint32_t)(e - s);
                     }
@@ -575,16 +597,16 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     uint32_t* const cnt = s_cnt + t * kBins;
     const int plane = planes[t];
     C.plane = plane;
-    double* const out_f64 = t == 0 ? T.out_f64 : T.out_f64_b;
-    uint32_t* const out_u32 = t == 0 ? T.out_u32 : T.out_u32_b;
+    AS1 double* const out_f64 = gp(t == 0 ? T.out_f64 : T.out_f64_b);
+    AS1 uint32_t* const out_u32 = gp(t == 0 ? T.out_u32 : T.out_u32_b);
     const bool overflow = s_overflow[t] != 0;
     if (overflow) {
         // depth beyond the single-level histogram somewhere: maximum, total and non-zero count by a pass of their own
         uint32_t vmax = 0;
         unsigned long long tsum = 0, nz = 0;
         for (uint32_t b = b0; b < b0 + nb; b++) {
-            const uint64_t bc = T.blks[b].cstart;
-            for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
+            const uint64_t bc = blks[b].cstart;
+            for_each_depth<kWaves>(C, bc, bc + blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
                 if (ok) { vmax = v > vmax ? v : vmax; tsum += v; nz += v ? 1u : 0u; }
             });
         }
@@ -647,7 +669,35 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     // q0,q1: sums below ranks lo / hi of the trimmed mean; q2..q7: values for p25, p50, p75 (ranks k-1 and k);
     // the ranks were worked out by the host (kernels.h: stats_queries) and travel in the record
     const unsigned long long lo = lane_u32(recA, 16), hi = lane_u32(recA, 17);
-    if (N > 0 && !overflow) {
+    if (kWaves == 1 && N > 0 && !overflow && s_hi[t] == 0u && N < (1ull << 23)) {
+        // One wave, every depth below kFastBins (nearly every intron of the small class): lane b takes bins 4b .. 4b + 3 in
+        // one LDS read, two wave scans give the counts and the weighted sums below every lane, and a query is a ballot
+        // (which lane holds rank r) plus a few selects inside that lane.  (N < 2^23: the weighted sums fit 32 bits.)
+        static_assert(kFastBins == 256u, "four bins per lane");
+        const uint4 c4 = reinterpret_cast<const uint4*>(cnt)[lane];
+        const uint32_t b4 = lane * 4u;
+        const uint32_t lt = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t w1 = c4.x * b4, w2 = w1 + c4.y * (b4 + 1u), w3 = w2 + c4.z * (b4 + 2u), lw = w3 + c4.w * (b4 + 3u);
+        const uint32_t ic = wave_inclusive_scan_dpp(lt), iw = wave_inclusive_scan_dpp(lw);
+        if (lane == 63u) s_total = iw;                       // sum of all depths
+        const uint32_t cx = c4.x, cxy = c4.x + c4.y, cxyz = cxy + c4.z;
+        for (int q = 0; q < kQueries; q++) {
+            if (!((qneed >> q) & 1u)) continue;              // wave-uniform
+            const uint32_t r = lane_u32(recA, 16u + q);
+            const uint64_t holds = __ballot(ic > r);         // (r < N: some lane's inclusive count exceeds it)
+            const uint32_t rr = r - (ic - lt);               // rank among this lane's bins (meaningful on the first lane of `holds`)
+            const uint32_t j = (rr >= cx ? 1u : 0u) + (rr >= cxy ? 1u : 0u) + (rr >= cxyz ? 1u : 0u);
+            const uint32_t below_c = j == 0u ? 0u : (j == 1u ? cx : (j == 2u ? cxy : cxyz));
+            const uint32_t below_w = j == 0u ? 0u : (j == 1u ? w1 : (j == 2u ? w2 : w3));
+            const uint32_t bin = b4 + j;
+            if (holds && lane == (uint32_t)__ffsll((long long)holds) - 1u) {
+                s_qval[q] = bin;
+                s_qsum[q] = (unsigned long long)(iw - lw) + below_w + (unsigned long long)bin * (rr - below_c);
+            }
+        }
+        if (lt) reinterpret_cast<uint4*>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    } else if (N > 0 && !overflow) {
         // single level: bins are the depths themselves
         uint32_t c[kBinsPerThread];
         uint32_t tot = 0;
@@ -698,6 +748,11 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             prev_bin = (uint32_t)bin;
             prev_left = lane_u32(ic, hl) - 1u - rr;                                // ranks of this bin behind rank r
         }
+        // (a wave's queries read only bins of its own threads, and a wave's LDS accesses keep their order: no barrier needed)
+        if (tot) {
+#pragma unroll
+            for (int j = 0; j < kBinsPerThread; j++) cnt[tid * kBinsPerThread + j] = 0;
+        }
         __syncthreads();
     } else if (N > 0) {
         // multi-level radix select, one descent per query; a sum query (q < 2) then adds the values below the selected one
@@ -714,8 +769,8 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
                 for (int k = tid; k < kBins; k += kThreads) cnt[k] = 0;
                 __syncthreads();
                 for (uint32_t b = b0; b < b0 + nb; b++) {
-                    const uint64_t bc = T.blks[b].cstart;
-                    for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
+                    const uint64_t bc = blks[b].cstart;
+                    for_each_depth<kWaves>(C, bc, bc + blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
                         const bool in = ok && (lv == 0 || (v >> (shift + kBinBits)) == prefix);
                         if (in) atomicAdd(&cnt[(v >> shift) & (uint32_t)(kBins - 1)], 1u);
                     });
@@ -749,8 +804,8 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             if (q < 2) {
                 unsigned long long part = 0;
                 for (uint32_t b = b0; b < b0 + nb; b++) {
-                    const uint64_t bc = T.blks[b].cstart;
-                    for_each_depth<kWaves>(C, bc, bc + T.blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
+                    const uint64_t bc = blks[b].cstart;
+                    for_each_depth<kWaves>(C, bc, bc + blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
                         if (ok && v < prefix) part += v;
                     });
                 }
@@ -764,6 +819,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             }
             if (tid == 0) { s_qval[q] = prefix; s_qsum[q] = below + (unsigned long long)prefix * r; }
         }
+        for (int k = tid; k < kBins; k += kThreads) cnt[k] = 0;            // (the histograms are zero between introns)
         __syncthreads();
     } else {
         __syncthreads();
@@ -803,11 +859,11 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
                 uint64_t lo_i = 0, hi_i = T.n_unique;
                 while (lo_i < hi_i) {
                     const uint64_t mid = lo_i + ((hi_i - lo_i) >> 1);
-                    if (T.ukeys[mid] < key0) lo_i = mid + 1; else hi_i = mid;
+                    if (gp(T.ukeys)[mid] < key0) lo_i = mid + 1; else hi_i = mid;
                 }
-                for (uint64_t u = lo_i; u < T.n_unique && u < lo_i + 2 && (T.ukeys[u] >> 1) == (key0 >> 1); u++) {
-                    const int d = (int)(T.ukeys[u] & 1ull);
-                    if (plane == 2 || plane == d) je += T.ucount[u];
+                for (uint64_t u = lo_i; u < T.n_unique && u < lo_i + 2 && (gp(T.ukeys)[u] >> 1) == (key0 >> 1); u++) {
+                    const int d = (int)(gp(T.ukeys)[u] & 1ull);
+                    if (plane == 2 || plane == d) je += gp(T.ucount)[u];
                 }
             }
         }
@@ -920,6 +976,9 @@ __global__ __launch_bounds__(256) void ir_rows_kernel(IntronTables T) {
     }
 }
 
+// the statistics kernels' table block in device memory (launch_intron_stats)
+__global__ void store_intron_tables_kernel(IntronTables T, IntronTables* dst) { *dst = T; }
+
 }   // namespace
 
 void launch_ir_rows(const IntronTables& T, hipStream_t s) {
@@ -930,13 +989,14 @@ void launch_ir_rows(const IntronTables& T, hipStream_t s) {
 // T.recs is laid out by size class (kernels.h: StatsClasses) and, inside a class, by workgroup: workgroup w of class c
 // walks records [wg_off[c][w], wg_off[c][w + 1]) (the host balanced the lists).  The 64-thread class keeps its flank
 // windows in a 64-entry LDS buffer: the host puts every intron into the 256-thread class when flank_len is larger.
-void launch_intron_stats(const IntronTables& T, const StatsClasses& K, hipStream_t s) {
-    if (T.dual) {       // both tables in one pass (T.directionality != 0; outputs out_* and out_*_b)
-        if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10, 2>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
-        if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL, 2>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+void launch_intron_stats(const IntronTables& T, IntronTables* d_T, const StatsClasses& K, hipStream_t s) {
+    hipLaunchKernelGGL(store_intron_tables_kernel, dim3(1), dim3(1), 0, s, T, d_T);
+    if (T.dual) {       // both tables in one pass (T.directionality != 0 or the vote; outputs out_* and out_*_b)
+        if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10, 2>), dim3(K.n_wg[0]), dim3(256), 0, s, d_T, K.wg_off[0], 0u);
+        if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL, 2>), dim3(K.n_wg[1]), dim3(64), 0, s, d_T, K.wg_off[1], K.n_wg[0]);
     } else {
-        if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10, 1>), dim3(K.n_wg[0]), dim3(256), 0, s, T, K.wg_off[0], 0u);
-        if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL, 1>), dim3(K.n_wg[1]), dim3(64), 0, s, T, K.wg_off[1], K.n_wg[0]);
+        if (K.n_wg[0]) hipLaunchKernelGGL((intron_stats_kernel<256, kStatsMaxFlank, STATS_INFLIGHT_BIG, 10, 1>), dim3(K.n_wg[0]), dim3(256), 0, s, d_T, K.wg_off[0], 0u);
+        if (K.n_wg[1]) hipLaunchKernelGGL((intron_stats_kernel<64, kStatsSmallFlank, STATS_INFLIGHT_SMALL, STATS_BITS_SMALL, 1>), dim3(K.n_wg[1]), dim3(64), 0, s, d_T, K.wg_off[1], K.n_wg[0]);
     }
 #ifdef STATS_PROF
     {
