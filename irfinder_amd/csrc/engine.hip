@@ -133,8 +133,6 @@ struct irf_ctx {
     DevBuf<uint64_t> ro_key_a, ro_key_b;
     DevBuf<uint32_t> ro_nblk, ro_chr, ro_start, ro_end, ro_off, ro_bs, ro_bl;
     DevBuf<uint8_t> ro_flags, ro_rd, ro_frag_recs;
-    DevBuf<uint2> ro_blk_recs;
-    DevBuf<uint32_t> ro_src_off;
     int reorder(dev::BatchDev& B);
     DevBuf<uint8_t> d_dirty;                     // which 64-byte lines of d_diff hold something (kernels.h: CountTables.dirty)
     // Spare plane sets for the following samples.  A set that irf_reset swapped out is dirty (its line marks say where) and is
@@ -959,21 +957,20 @@ int irf_ctx::reorder(dev::BatchDev& B) {
     if (e == hipSuccess) e = ro_bl.reserve(nb + 4);
     if (e == hipSuccess) e = ro_rd.reserve(nb + 4);
     if (e == hipSuccess) e = ro_frag_recs.reserve(n * dev::reorder_frag_rec_bytes());
-    if (e == hipSuccess) e = ro_blk_recs.reserve(nb);
-    if (e == hipSuccess) e = ro_src_off.reserve(n);
     const uint64_t ws_need = std::max(dev::radix_workspace_elems(n), dev::scan_workspace_elems(n + 1));
     if (e == hipSuccess && ws_need > d_ws_sort.cap) e = d_ws_sort.reserve(ws_need);
     if (e != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the batch reorder buffers failed");
-    dev::launch_reorder_keys(B, d_chr_base.p, n_chr, ro_key_a.p, ro_frag_recs.p, ro_blk_recs.p, d_err.p, stream);
+    const uint64_t top = full_size >> dev::kReorderShift;        // (the bin sits in bits kReorderKeyBinShift and up)
+    if (top >> (64 - dev::kReorderKeyBinShift)) return fail(IRF_E_RANGE, "IRF_ORDER_ANY: the chromosomes of this context span more than 2^34 positions");
+    dev::launch_reorder_keys(B, d_chr_base.p, n_chr, ro_key_a.p, ro_frag_recs.p, d_err.p, stream);
     uint64_t* ks = ro_key_a.p; uint64_t* kd = ro_key_b.p;
-    const uint64_t top = full_size >> dev::kReorderShift;        // (the bin sits in bits 32 and up, the fragment index below it)
-    for (int shift = 0; shift < 32 && (top >> shift) != 0; shift += 8) {
-        dev::launch_radix_pass(ks, kd, nullptr, nullptr, n, 32 + shift, d_ws_sort.p, stream);
+    for (int shift = 0; shift < 64 - dev::kReorderKeyBinShift && (top >> shift) != 0; shift += 8) {
+        dev::launch_radix_pass(ks, kd, nullptr, nullptr, n, dev::kReorderKeyBinShift + shift, d_ws_sort.p, stream);
         std::swap(ks, kd);
     }
-    dev::launch_reorder_frags(B.n_frag, ro_frag_recs.p, ks, ro_chr.p, ro_flags.p, ro_start.p, ro_end.p, ro_nblk.p, ro_src_off.p, stream);
+    dev::launch_reorder_counts(B.n_frag, ks, ro_frag_recs.p, ro_nblk.p, stream);
     dev::launch_exclusive_scan_u32(ro_nblk.p, ro_off.p, n + 1, d_ws_sort.p, stream);
-    dev::launch_reorder_blocks(B.n_frag, B.n_blk, ro_blk_recs.p, ro_src_off.p, ro_off.p, ro_bs.p, ro_bl.p, ro_rd.p, stream);
+    dev::launch_reorder_gather(B, ro_frag_recs.p, ks, ro_off.p, ro_chr.p, ro_flags.p, ro_start.p, ro_end.p, ro_bs.p, ro_bl.p, ro_rd.p, stream);
     HIP_TRY(hipGetLastError());
     B.frag_chr = ro_chr.p; B.frag_flags = ro_flags.p; B.frag_start = ro_start.p; B.frag_end = ro_end.p; B.frag_blk_off = ro_off.p;
     B.blk_start = ro_bs.p; B.blk_len = ro_bl.p; B.blk_read = ro_rd.p;

@@ -140,17 +140,18 @@ inline size_t dirty_map_bytes(uint64_t plane_stride) { return (size_t)((plane_st
 
 // ---- batches in any order (reorder.hip) -------------------------------------
 constexpr int kReorderShift = 8;       // fragments are binned by (chromosome base + start) >> kReorderShift
-// keys for the radix passes (bin << 32 | fragment index: the index travels in the key, the passes move 8 bytes per
-// record and sort on bits 32 and up), and the array-of-structs copies the two gathers read (frag_recs: n_frag records of
-// reorder_frag_rec_bytes(), blk_recs: n_blk x 8 bytes); checks the CSR offsets (ERR_CSR) and the packed block fields
+// key of the radix passes = bin << kReorderKeyBinShift | min(block count, kReorderKeyNblkMax) << 32 | fragment index: the
+// passes move 8 bytes per record and sort on the bin's bits only (bin < 2^26: up to 2^34 positions).  frag_recs: n_frag
+// records of reorder_frag_rec_bytes() (reorder.hip).  launch_reorder_keys also checks the CSR offsets (ERR_CSR) and the
+// packed block fields (ERR_BLOCK_RANGE).
+constexpr int kReorderKeyBinShift = 38;
+constexpr uint32_t kReorderKeyNblkMax = 63;
 size_t reorder_frag_rec_bytes();
-void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, void* frag_recs, void* blk_recs,
-                         uint32_t* err_flags, hipStream_t s);
+void launch_reorder_keys(const BatchDev& B, const uint64_t* chr_base, uint32_t n_chr, uint64_t* keys, void* frag_recs, uint32_t* err_flags, hipStream_t s);
 // nblk: n_frag + 1 elements (the last one 0: its exclusive scan is the new offsets array, total included)
-void launch_reorder_frags(uint32_t n_frag, const void* frag_recs, const uint64_t* sorted_keys, uint32_t* chr, uint8_t* flags, uint32_t* start, uint32_t* end,
-                          uint32_t* nblk, uint32_t* src_off, hipStream_t s);
-void launch_reorder_blocks(uint32_t n_frag, uint32_t n_blk, const void* blk_recs, const uint32_t* src_off, const uint32_t* new_off, uint32_t* bs, uint32_t* bl, uint8_t* rd,
-                           hipStream_t s);
+void launch_reorder_counts(uint32_t n_frag, const uint64_t* sorted_keys, const void* frag_recs, uint32_t* nblk, hipStream_t s);
+void launch_reorder_gather(const BatchDev& B, const void* frag_recs, const uint64_t* sorted_keys, const uint32_t* new_off, uint32_t* chr, uint8_t* flags,
+                           uint32_t* start, uint32_t* end, uint32_t* bs, uint32_t* bl, uint8_t* rd, hipStream_t s);
 
 // ---- scans ----------------------------------------------------------------
 constexpr uint32_t kScanTile = 4096;

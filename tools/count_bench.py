@@ -26,6 +26,9 @@ else:
     host = world.sort_by_coordinate(world.concat_batches(bs))
     cols = {n: getattr(host, n) for n in names}
     np.savez(cache, **cols)
+shuffle = bool(os.environ.get("IRF_BENCH_SHUFFLE"))         # the same fragments in a random order, binned on the device (IRF_ORDER_ANY)
+if shuffle:
+    cols = {n: getattr(Batch(**cols).select(np.random.default_rng(7).permutation(len(cols["frag_chr"]))), n) for n in names}
 n_frag, n_blk = len(cols["frag_chr"]), len(cols["blk_start"])
 dev = torch.device("cuda:0")
 dten = {n: torch.from_numpy(cols[n]).to(dev) for n in names}
@@ -33,9 +36,13 @@ db = engine.device_batch(dten, n_frag, n_blk)
 ref = engine.RefTables.from_texts(ann.ref_texts(hide_sj_frac=0.1, hide_seed=20240808))
 e = engine.Engine(ref)
 e.chr_map_update(ann.chr_names, ann.chr_lens)
-ms = []
+if shuffle:
+    e.set_input_order(1)
+ms, wall = [], []
 for r in range(reps):
-    e.reset(); e.submit(db); e.finalize()
+    e.sync(); t0 = time.perf_counter()
+    e.reset(); e.submit(db); e.finalize(); e.sync()
+    wall.append((time.perf_counter() - t0) * 1e3)
     t = e.timing()
     ms.append(t["count_ms"])
     if os.environ.get("IRF_CHECK_EVERY_REP"):
@@ -45,4 +52,5 @@ for r in range(reps):
 res = e.results()
 chk = (int(res["chr_cnt"].sum()), int(res["sp_cnt"].astype(np.uint64).sum()), int(res["junc_cnt"].astype(np.uint64).sum()), int(res["roi_cnt"].sum()),
        float(np.nansum(res["nondir"]["intron_depth"])))
-print("lib=%s count_ms min %.3f all %s stats_ms %.3f check %s" % (os.path.basename(engine.LIB_PATH), min(ms), ["%.3f" % m for m in ms], t["stats_ms"], chk), flush=True)
+print("lib=%s%s count_ms min %.3f all %s stats_ms %.3f step wall ms min %.3f check %s" % (os.path.basename(engine.LIB_PATH), " shuffled+ORDER_ANY" if shuffle else "", min(ms),
+      ["%.3f" % m for m in ms], t["stats_ms"], min(wall), chk), flush=True)
