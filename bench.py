@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=50_000_000, help="pairs per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --pairs per GPU (the driver's contract); strong: ONE sample of --total-pairs split over the GPUs by chromosome (BASELINE configs[3])")
+    ap.add_argument("--total-pairs", type=int, default=400_000_000, help="--scaling strong: pairs of the whole sample")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--stranded", type=int, default=0)
     ap.add_argument("--order", choices=["sorted", "random"], default="sorted")
@@ -112,6 +115,12 @@ def main():
     else:
         masks = irfdist.shard_chromosomes(lens, world)
     owned = masks[rank]
+    # weak scaling: every GPU counts --pairs pairs on its chromosomes; strong scaling: one sample of --total-pairs pairs, a
+    # rank gets the share of it that falls on its chromosomes (expected reads, as the pilot / a BAI index gives them)
+    pairs_rank = args.pairs
+    if args.scaling == "strong":
+        pairs_rank = int(round(args.total_pairs * (loads[rank] / loads.sum()))) if world > 1 else args.total_pairs
+    total_pairs = args.total_pairs if args.scaling == "strong" else world * args.pairs
     # this rank's simulator draws only from its own chromosomes
     import copy
     ann_r = copy.copy(ann)
@@ -124,7 +133,7 @@ def main():
         sim._keep.append(np.ascontiguousarray(np.cumsum(cl) / cl.sum()))
         sim.model.chr_cdf = sim._keep[-1].ctypes.data
     t0 = time.time()
-    batches, rstats = synth_world.generate_batches(sim, 0, args.pairs, chunk=500_000, threads=args.threads)
+    batches, rstats = synth_world.generate_batches(sim, 0, pairs_rank, chunk=500_000, threads=args.threads)
     gen_s = time.time() - t0
     host = synth_world.concat_batches(batches)
     del batches
@@ -136,8 +145,8 @@ def main():
     n_frag, n_blk = host.n_frag, host.n_blk
     log("rank %d: %d fragments, %d blocks (%.2f/frag) generated+assembled in %.1fs (%.2f M pairs/s host, %d threads); "
         "classes short/intersect/long = %d/%d/%d" % (rank, n_frag, n_blk, n_blk / max(n_frag, 1), gen_s,
-                                                     args.pairs / gen_s / 1e6, args.threads, rstats["n_pairs_short"],
-                                                     rstats["n_pairs_intersect"], rstats["n_pairs_long"]))
+                                                     pairs_rank / gen_s / 1e6, args.threads, rstats.get("n_pairs_short", 0),
+                                                     rstats.get("n_pairs_intersect", 0), rstats.get("n_pairs_long", 0)))
     t0 = time.time()
     dten = {n: torch.from_numpy(getattr(host, n)).to(dev) for n, _ in Batch.FIELDS}
     torch.cuda.synchronize()
@@ -304,7 +313,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / max(args.steps, 1) * 1e3
-    value = world * args.pairs / (dt / max(args.steps, 1))
+    value = total_pairs / (dt / max(args.steps, 1))
     for k in kt:
         kt[k] /= max(args.steps, 1)
 
@@ -354,7 +363,7 @@ def main():
     PMC_FILE = "r04_pmc_summary.json"        # round 3's counters (profiles/README.md: files are named rNN = BENCH round + 1)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-        if world == 1 and args.genome == "grch38" and args.pairs == 50_000_000 and not args.stranded and args.order == "sorted":
+        if world == 1 and args.genome == "grch38" and pairs_rank == 50_000_000 and not args.stranded and args.order == "sorted":
             # the counters were collected on a particular version of the kernels: a later change of their sources makes the
             # committed figure stale, and the line then says so instead of repeating it
             import hashlib
@@ -495,7 +504,7 @@ def main():
                     c_ms += eng.timing()["count_ms"]
                     best_c = t1 - t0 if rep == 1 else min(best_c, t1 - t0)
             same = bool(np.array_equal(out["ir_f64"].numpy(), out["got"]["ir_f64"].cpu().numpy()))
-            return {"ms_per_step": round(best_c * 1e3, 3), "pairs_per_s": round(args.pairs / best_c, 1), "count_ms": round(c_ms / n_rep, 4),
+            return {"ms_per_step": round(best_c * 1e3, 3), "pairs_per_s": round(pairs_rank / best_c, 1), "count_ms": round(c_ms / n_rep, 4),
                     "same_rows_as_sorted_run": same}
 
         from irfinder_amd._abi import ORDER_ANY, ORDER_SORTED
@@ -656,7 +665,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             best = t1 - t0 if best is None else min(best, t1 - t0)
-        extra["pcie_inclusive"] = {"pairs_per_s": round(args.pairs / best, 1), "ms_per_sample": round(best * 1e3, 2), "host_batches": n_cut,
+        extra["pcie_inclusive"] = {"pairs_per_s": round(pairs_rank / best, 1), "ms_per_sample": round(best * 1e3, 2), "host_batches": n_cut,
                                    "GBps_over_pcie": round(in_bytes / best / 1e9, 1),
                                    "note": "same sample from page-locked host batches through irf_submit_batch (double-buffered staging on the copy stream), "
                                            "finalize, IR table to the host; includes the host-side check of the CSR offsets"}
@@ -666,10 +675,11 @@ def main():
     line = {
         "metric": "read-pairs/sec to IR table", "value": round(value, 1), "unit": "read-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u64 counters, f64 table columns",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int32/u64 counters, f64 table columns",
         "data": "synthetic",
-        "config": {"workload": "%d M simulated 2x%dbp pairs per GPU, %s synthetic GENCODE-like reference (%d introns), %s, %s order%s" % (
-            args.pairs // 1_000_000, args.read_len, {"grch38": "full GRCh38-sized", "chr22": "chr22-only", "toy": "toy"}[args.genome],
+        "config": {"workload": "%s simulated 2x%dbp pairs%s, %s synthetic GENCODE-like reference (%d introns), %s, %s order%s" % (
+            ("%d M" % (args.pairs // 1_000_000)) if args.scaling == "weak" else ("one sample of %d M" % (args.total_pairs // 1_000_000)), args.read_len,
+            " per GPU" if args.scaling == "weak" else " split over the GPUs by chromosome", {"grch38": "full GRCh38-sized", "chr22": "chr22-only", "toy": "toy"}[args.genome],
             ann.n_intron, "stranded" if args.stranded else "unstranded", args.order + (
                 ", %.0f %% of ref-sj.ref withheld from the engine (novel junctions)" % (100 * args.novel_frac) if args.novel_frac > 0 else ""),
             ", chromosome-sharded over %d GPUs with RCCL collection of the tables" % world if world > 1 else ""),

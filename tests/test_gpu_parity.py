@@ -474,6 +474,38 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
             assert filecmp.cmp(out / f, cpu / f, shallow=False), (tag, f)
 
 
+def test_rccl_collect_program_with_a_one_rank_communicator(tmp_path):
+    """irfinder_amd/irf_rccl_collect (host/rccl_collect_main.cpp + rccl_collect.h: the C recipe of INTEGRATION.md §5,
+    linked against librccl) as a fresh child process with a ONE-rank communicator: ncclCommInitRank, the all-reduce of
+    the vote, the eight ncclReduce calls with their dtypes and the stream ordering are executed for real; the output
+    files must equal the oracle CLI's.  (More ranks need more GPUs than the test box has: tests/test_gpu_distributed.py
+    covers the multi-rank arithmetic through torch.distributed.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ann, sim = small_world(seed=37, stranded=True)
+    bam = sim.bam(0, 20000)
+    names = ["ref-cover.bed", "ref-sj.ref", "ref-read-continues.ref", "ref-ROI.bed"]
+    sj = "".join(l for i, l in enumerate(ann.sj_ref.splitlines(True)) if i % 3)       # a third of ref-sj withheld: novel junctions
+    for n, t in zip(names, (ann.cover_bed, sj, ann.read_continues_ref, ann.roi_bed)):
+        (tmp_path / n).write_text(t)
+    (tmp_path / "in.bam.raw").write_bytes(bam)
+    refs = [str(tmp_path / n) for n in names]
+    outs = {}
+    for tag, exe in (("cpu", os.path.join(root, "oracle", "irfinder_oracle")), ("rccl", os.path.join(root, "irfinder_amd", "irf_rccl_collect"))):
+        out = tmp_path / tag
+        out.mkdir()
+        env = dict(os.environ, IRF_RANK="0", IRF_WORLD="1", IRF_DEVICE="0")
+        with open(tmp_path / "in.bam.raw", "rb") as fh:
+            p = subprocess.run([exe, str(out)] + refs, stdin=fh, capture_output=True, timeout=180, env=env)
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        outs[tag] = p.stdout
+    assert outs["rccl"].endswith(outs["cpu"]) and outs["cpu"]        # (librccl announces its versions on stdout first)
+    files = sorted(os.listdir(tmp_path / "cpu"))
+    assert files == sorted(os.listdir(tmp_path / "rccl")) and len(files) == 6
+    for f in files:
+        assert filecmp.cmp(tmp_path / "cpu" / f, tmp_path / "rccl" / f, shallow=False), f
+
+
 def test_chromosome_shards_sum_to_the_whole_P3():
     """Two contexts with complementary `owned` masks (what two ranks do), each fed the WHOLE batch (foreign fragments
     are ignored), the global strandedness vote imposed on both: the owner's rows / counters equal the single run's."""

@@ -27,6 +27,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name)
 
 
+def test_rccl_collection_recipe_is_plain_c_and_its_program_is_built(tmp_path):
+    """host/rccl_collect.h (the one-process-per-GPU collection over RCCL) compiles as C99 against
+    <rccl/rccl.h>, and the program around it was built and links librccl (its GPU run: test_gpu_parity.py)."""
+    src = tmp_path / "rc.c"
+    src.write_text('#include "irfinder_amd/host/rccl_collect.h"\nint main(void) { return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + ROOT, "-fsyntax-only", str(src)])
+    exe = os.path.join(ROOT, "irfinder_amd", "irf_rccl_collect")
+    assert os.path.exists(exe)
+    needed = subprocess.check_output(["readelf", "-d", exe]).decode()
+    assert "librccl" in needed and "libirfhip" in needed
+
+
 def test_params_defaults_match_oracle_and_struct_size():
     a, b = engine.default_params(), orc.default_params()
     assert a.struct_size == C.sizeof(IrfParams) == b.struct_size
