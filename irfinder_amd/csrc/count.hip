@@ -976,17 +976,22 @@ void launch_sparse_clear(int32_t* planes, uint8_t* dirty, uint64_t plane_stride,
     hipLaunchKernelGGL(sparse_clear_kernel, dim3((uint32_t)(wgs < kClearWgs ? wgs : kClearWgs)), dim3(256), 0, s, planes, dirty, plane_stride, n_groups);
 }
 
-void launch_count(const CountTables& T, CountTables* d_T, CountTables* shadow, const BatchDev& B, hipStream_t s) {
+void launch_count_prepare(const CountTables& T, CountTables* d_T, CountTables* shadow, const BatchDev& B, hipStream_t s) {
     if (B.n_frag == 0) return;
     if (memcmp(&T, shadow, sizeof T) != 0) {
         hipLaunchKernelGGL(store_tables_kernel, dim3(1), dim3(1), 0, s, T, d_T);
         *shadow = T;
     }
     const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
+    hipLaunchKernelGGL(chunk_origin_kernel, dim3((n_chunks + 255u) / 256u), dim3(256), 0, s, T, B, n_chunks);
+}
+
+void launch_count(CountTables* d_T, const BatchDev& B, hipStream_t s) {
+    if (B.n_frag == 0) return;
+    const uint32_t n_chunks = (B.n_frag + kChunk - 1u) / kChunk;
     const uint32_t n_slices = (n_chunks + kSlice - 1u) / kSlice;
     const uint32_t most = 256u * K_WGS_PER_CU;
     const uint32_t blocks = n_slices < most ? n_slices : most;
-    hipLaunchKernelGGL(chunk_origin_kernel, dim3((n_chunks + 255u) / 256u), dim3(256), 0, s, T, B, n_chunks);
     hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(kThreads), 0, s, d_T, B);
 #ifdef COUNT_PROF
     {

@@ -264,6 +264,7 @@ struct irf_ctx {
     int finalize();
     int finalize_directional(int32_t dirn);
     int settle();
+    int queue_spare_clears();
     int fetch_results();
     int export_col(uint32_t what, void* dst, uint64_t* n_out);
     int import_col(uint32_t what, const void* src, uint64_t n);
@@ -930,8 +931,9 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
         E.count_events.emplace_back(a, z);
     }
     auto& evp = E.count_events[E.count_events_used++];
-    HIP_TRY(hipEventRecord(evp.first, stream));
-    dev::launch_count(count_tables(), d_ctab.p, &ctab_shadow, B, stream);
+    dev::launch_count_prepare(count_tables(), d_ctab.p, &ctab_shadow, B, stream);
+    HIP_TRY(hipEventRecord(evp.first, stream));        // (count_ms = the count kernel itself, as rocprofv3 times it)
+    dev::launch_count(d_ctab.p, B, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(evp.second, stream));
     TRY(flush_exports());            // (the last sample's held-back table copies run under this count kernel)
@@ -1010,6 +1012,57 @@ dev::IntronTables irf_ctx::intron_tables(int t, int dirn, bool dual) {
 
 void irf_ctx::launch_stats(int t, int dirn, bool dual) {
     dev::launch_intron_stats(intron_tables(t, dirn, dual), d_itab.p + 2, stats_classes, stream);
+}
+
+// The following samples' planes (PlaneSet spare[]), cleared on the side stream.  Called by irf_finalize BEHIND the
+// statistics kernels and the rows: the clear then runs into the next sample's count kernel and costs it 0.1 ms (2.46 ->
+// 2.56 ms at 50 M pairs); queued in front of the statistics kernels it cost those 0.3 ms (1.9 -> 2.2 ms, measured with
+// one and with two workgroups per CU), so this is the cheaper place.
+int irf_ctx::queue_spare_clears() {
+    if (plane_stride) {
+        // (a set that is cleared for the FIRST time is a full memset, 5 GB: the first two samples of a context pay that once;
+        //  afterwards only the lines the sample marked are written, 0.8 GB)
+        const size_t n_seg2 = 2 * plane_stride / dev::kDepthSegment;
+        bool waited = false;
+        for (int k = 0; k < 2; k++) {
+            PlaneSet& sp = spare[k];
+            if (sp.clean) continue;
+            const bool had = sp.allocated(plane_stride);
+            // a first spare set when it leaves room for what the next sample may still grow (junction buffers, the reorder
+            // copies: a set's size again, at least 1 GiB); the second one with it when the device has plenty of room (three
+            // more sets would still fit), else never
+            if (!had) {
+                size_t free_b = 0, total_b = 0;
+                const size_t set_b = (size_t)2 * plane_stride * sizeof(int32_t);
+                const size_t need_b = k == 0 ? set_b + std::max<size_t>(set_b, (size_t)1 << 30) : 3 * set_b;
+                if ((k == 1 && !spare[0].allocated(plane_stride)) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need_b) { (void)hipGetLastError(); continue; }
+            }
+            if (sp.diff.reserve(2 * plane_stride) != hipSuccess || sp.seg_sum.reserve(n_seg2) != hipSuccess ||
+                sp.dirty.reserve(dev::dirty_map_bytes(plane_stride)) != hipSuccess) {
+                (void)hipGetLastError();           // no room: without a spare set irf_reset clears the planes in line
+                sp.release();
+                continue;
+            }
+            if (!waited) {
+                HIP_TRY(hipEventRecord(ev_stats_done, stream));
+                HIP_TRY(hipStreamWaitEvent(clear_stream, ev_stats_done, 0));
+                waited = true;
+            }
+            if (had) {
+                // this set held a sample's planes: only the lines that sample marked hold anything (a fifth of them at 50 M pairs)
+                dev::launch_sparse_clear(sp.diff.p, sp.dirty.p, plane_stride, clear_stream);
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipMemsetAsync(sp.diff.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
+                HIP_TRY(hipMemsetAsync(sp.dirty.p, 0, dev::dirty_map_bytes(plane_stride), clear_stream));
+            }
+            HIP_TRY(hipMemsetAsync(sp.seg_sum.p, 0, n_seg2 * sizeof(uint32_t), clear_stream));
+            HIP_TRY(hipEventRecord(sp.cleared, clear_stream));
+            sp.clean = true;
+            sp.seq = ++clear_seq;
+        }
+    }
+    return 0;
 }
 
 int irf_ctx::finalize() {
@@ -1152,49 +1205,7 @@ int irf_ctx::finalize() {
     else dev::launch_ir_rows(intron_tables(0, 0, false), stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], stream));
-    if (plane_stride) {
-        // the following samples' planes: cleared on the side stream as soon as the statistics kernels have finished (a
-        // memset UNDER them costs them more than its own time)
-        const size_t n_seg2 = 2 * plane_stride / dev::kDepthSegment;
-        bool waited = false;
-        for (int k = 0; k < 2; k++) {
-            PlaneSet& sp = spare[k];
-            if (sp.clean) continue;
-            const bool had = sp.allocated(plane_stride);
-            // a first spare set when it leaves room for what the next sample may still grow (junction buffers, the reorder
-            // copies: a set's size again, at least 1 GiB); the second one with it when the device has plenty of room (three
-            // more sets would still fit), else never
-            if (!had) {
-                size_t free_b = 0, total_b = 0;
-                const size_t set_b = (size_t)2 * plane_stride * sizeof(int32_t);
-                const size_t need_b = k == 0 ? set_b + std::max<size_t>(set_b, (size_t)1 << 30) : 3 * set_b;
-                if ((k == 1 && !spare[0].allocated(plane_stride)) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need_b) { (void)hipGetLastError(); continue; }
-            }
-            if (sp.diff.reserve(2 * plane_stride) != hipSuccess || sp.seg_sum.reserve(n_seg2) != hipSuccess ||
-                sp.dirty.reserve(dev::dirty_map_bytes(plane_stride)) != hipSuccess) {
-                (void)hipGetLastError();           // no room: without a spare set irf_reset clears the planes in line
-                sp.release();
-                continue;
-            }
-            if (!waited) {
-                HIP_TRY(hipEventRecord(ev_stats_done, stream));
-                HIP_TRY(hipStreamWaitEvent(clear_stream, ev_stats_done, 0));
-                waited = true;
-            }
-            if (had) {
-                // this set held a sample's planes: only the lines that sample marked hold anything (a fifth of them at 50 M pairs)
-                dev::launch_sparse_clear(sp.diff.p, sp.dirty.p, plane_stride, clear_stream);
-                HIP_TRY(hipGetLastError());
-            } else {
-                HIP_TRY(hipMemsetAsync(sp.diff.p, 0, 2 * plane_stride * sizeof(int32_t), clear_stream));
-                HIP_TRY(hipMemsetAsync(sp.dirty.p, 0, dev::dirty_map_bytes(plane_stride), clear_stream));
-            }
-            HIP_TRY(hipMemsetAsync(sp.seg_sum.p, 0, n_seg2 * sizeof(uint32_t), clear_stream));
-            HIP_TRY(hipEventRecord(sp.cleared, clear_stream));
-            sp.clean = true;
-            sp.seq = ++clear_seq;
-        }
-    }
+    TRY(queue_spare_clears());
     // Everything is queued.  The host does not wait for it here: whatever reads a result (irf_get_results, an export that
     // is not IRF_COL_NO_SYNC, irf_get_timing, irf_get_depth), irf_reset and irf_sync wait first (settle()), and exports with
     // IRF_COL_NO_SYNC queue behind it.  A caller that counts sample after sample thus prepares the next sample's

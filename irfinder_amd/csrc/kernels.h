@@ -129,7 +129,10 @@ struct BatchDev {
 // The count kernel reads its tables through a pointer (the block is ~50 dwords: as a by-value argument it filled the scalar
 // registers): d_T is a device copy of T that launch_count refreshes (a one-thread kernel on the stream) whenever T differs
 // from *shadow, the host's record of what d_T holds.
-void launch_count(const CountTables& T, CountTables* d_T, CountTables* shadow, const BatchDev& B, hipStream_t s);
+// launch_count_prepare: the table block into device memory when it changed (shadow = the host's copy of what is there) and
+// the chunk origins of the batch; launch_count: the count kernel alone (the engine's timing events bracket only that)
+void launch_count_prepare(const CountTables& T, CountTables* d_T, CountTables* shadow, const BatchDev& B, hipStream_t s);
+void launch_count(CountTables* d_T, const BatchDev& B, hipStream_t s);
 uint32_t count_chunk_fragments();      // fragments per entry of CountTables::chunk_origin
 // difference events of the reads on known junctions, from the junction counters: after the sample's last count kernel,
 // before the carry scan (once per sample)
