@@ -200,6 +200,21 @@ const char* irf_last_error(const irf_ctx* ctx);
 int irf_chr_map_update(irf_ctx* ctx, uint32_t n_chr, const char* const* names,
                        const uint32_t* lens, const uint8_t* owned);
 
+/* Multi-GPU, a reference split between contexts (no upstream counterpart: upstream is one process; SURVEY.md §8 e).
+ * As irf_chr_map_update, plus for every OWNED reference the part [own_start[i], own_end[i]) this context owns (NULL, NULL:
+ * whole references; an end beyond the reference's length = to its end).  The cut must lie where no intron (with its
+ * measured blocks) spans it: an intergenic gap (ROIs may span it — ref-ROI.bed lists the intergenic regions themselves).  Rules:
+ *   - introns, SpansPoints and ref-sj junctions belong to the context that owns their START (left end, position);
+ *     the others do not exist for this context (their rows / counters stay zero, so the shards' tables still add up);
+ *   - a fragment is counted by every context whose part it reaches into (so a fragment across the cut adds its depth and
+ *     its junctions on both sides, no exchange needed); fragments elsewhere on the reference are ignored;
+ *   - FragmentsInChr and FragmentsInROI count a fragment where its start lies (every context holds all ROIs of the
+ *     reference); a novel junction is reported by the owner of its left end
+ *     (irf_export_junctions / irf_get_results; the packed IRF_COL_JUNC_* columns are refused for such a context).
+ * irf_gather and the RCCL recipe work unchanged.                                                                     */
+int irf_chr_map_update_ranges(irf_ctx* ctx, uint32_t n_chr, const char* const* names, const uint32_t* lens, const uint8_t* owned,
+                              const uint32_t* own_start, const uint32_t* own_end);
+
 /* Replaces n_frag calls of ReadBlockProcessor::ProcessBlocks on each of
  * FragmentsInChr, FragmentsInROI, JunctionCount, SpansPoint, CoverageBlocks
  * and FragmentsMap.  Asynchronous: host arrays must stay valid and unmodified

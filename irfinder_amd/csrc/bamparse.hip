@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void pair_tile_last_kernel(const uint32_t
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) tile_last[blockIdx.x] = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
 }
 
@@ -200,14 +200,14 @@ __global__ __launch_bounds__(kThreads) void pair_tile_scan_kernel(const uint32_t
         const uint32_t v = t < n_tiles ? tile_last[t] : 0u;
         const uint32_t inc = wave_inclusive_max(v, lane);
         if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
+        wg_barrier();
         uint32_t before = carry;
         for (uint32_t w = 0; w < wave; w++) before = max(before, s_w[w]);
         uint32_t excl = __shfl_up(inc, 1);
         if (lane == 0) excl = 0;
         if (t < n_tiles) tile_carry[t] = max(before, excl);
         carry = max(max(carry, max(s_w[0], s_w[1])), max(s_w[2], s_w[3]));
-        __syncthreads();
+        wg_barrier();
     }
 }
 
@@ -360,7 +360,7 @@ __device__ __forceinline__ uint32_t last_unpaired_before(const AssembleArgs& A, 
     }
     const uint32_t inc = wave_inclusive_max(m, lane);
     if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
+    wg_barrier();
     uint32_t before = A.tile_carry[blockIdx.x];
     for (uint32_t w = 0; w < wave; w++) before = max(before, s_w[w]);
     uint32_t excl = __shfl_up(inc, 1);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs A) {
     if (!WRITE && threadIdx.x < RS_COUNT) s_stats[threadIdx.x] = 0;
     const uint32_t i0 = blockIdx.x * kPairTile + threadIdx.x * kPerThread;
     uint32_t last = 0;
-    if (A.mate) __syncthreads();
+    if (A.mate) wg_barrier();
     else last = last_unpaired_before(A, i0, s_w);         // (barrier inside: s_stats is zeroed for everyone)
     uint32_t st[RS_COUNT];
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs A) {
             for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
             if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_stats[k], v);
         }
-        __syncthreads();
+        wg_barrier();
         if (threadIdx.x < RS_COUNT && s_stats[threadIdx.x]) atomicAdd(&A.stats[threadIdx.x], s_stats[threadIdx.x]);
     }
 }
@@ -468,7 +468,7 @@ __device__ __forceinline__ unsigned long long name_hash(const uint8_t* name, uin
 __global__ __launch_bounds__(kThreads) void join_keys_kernel(JoinArgs J) {
     __shared__ unsigned long long s_stats[2];
     if (threadIdx.x < 2) s_stats[threadIdx.x] = 0;
-    __syncthreads();
+    wg_barrier();
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     unsigned long long nrec = 0, nnuc = 0;
     if (i < J.n_rec) {
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void join_keys_kernel(JoinArgs J) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { nrec += __shfl_xor(nrec, d); nnuc += __shfl_xor(nnuc, d); }
     if ((threadIdx.x & 63) == 0) { if (nrec) atomicAdd(&s_stats[0], nrec); if (nnuc) atomicAdd(&s_stats[1], nnuc); }
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) {
         if (s_stats[0]) atomicAdd(&J.stats[RS_RECORDS], s_stats[0]);
         if (s_stats[1]) atomicAdd(&J.stats[RS_NUCLEOTIDES], s_stats[1]);

@@ -551,13 +551,13 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
         s_t[0][threadIdx.x] = c;
-        __syncthreads();
+        wg_barrier();
         for (int k = 1; k < 4; k++) {
             c = (c >> 8) ^ s_t[0][c & 0xffu];
             s_t[k][threadIdx.x] = c;
         }
     }
-    __syncthreads();
+    wg_barrier();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t mi = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (mi >= n_members) return;

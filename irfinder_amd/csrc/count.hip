@@ -141,6 +141,7 @@ constexpr unsigned long long kOqRoi = 3ull << 62;       // | count << 32 | row o
 
 #define AS1 __attribute__((address_space(1)))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // Pointers read out of the table block are generic to the compiler (flat instructions: both wait counters); cast to the
 // global address space where they are used.
 template <class X> __device__ __forceinline__ AS1 X* gp(X* p) { return (AS1 X*)p; }
@@ -194,13 +195,6 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {          // lane 
     v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
     v = umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
     return v;
-}
-// Workgroup barrier with the wave's own LDS operations (the block phase's atomics among them) completed first.  The wait is
-// spelled out: in front of a barrier at a loop header the compiler was seen to emit none (ROCm 7.2, gfx950: s_barrier right
-// behind the back edge's ds_max_u32), and a read behind the barrier then missed an update issued in front of it.
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
 }
 // lane i gets lane i + 1's value (lane 63: 0); every lane of the wave must be active
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) {
@@ -636,7 +630,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
                     if (in && !chr_ok) err |= ERR_CHR_RANGE;
                     u32x4 rec = S.chrtab[chr_ok && chr[j] < kChrTab ? chr[j] : 0u];
                     if (chr_ok && chr[j] >= kChrTab) rec = chr_rec[chr[j]];
-                    const bool counted = chr_ok && rec.w != 0u;
+                    bool counted = chr_ok && rec.w != 0u;
+                    bool in_chr_count = counted;
+                    if (counted && rec.w == 2u) {
+                        // a reference this context owns in part (irf_chr_map_update_ranges): a fragment that does not reach
+                        // into [x, y) is ignored; one that does is counted whole (it may add to owned features on this side
+                        // of the cut), but FragmentsInChr and FragmentsInROI belong to the context that owns its start
+                        const u32x2 own = ((const AS1 u32x2*)T.chr_own)[chr[j]];
+                        counted = fs[j] < own.y && fe[j] > own.x;
+                        in_chr_count = counted && fs[j] >= own.x;
+                    }
                     const uint64_t base = (uint64_t)rec.y << 32 | rec.x;
                     const uint32_t clen = rec.z;
                     const uint32_t fdir = flg[j] & 1u;
@@ -644,11 +647,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
                     S.facts[j * kThreads + tid] = counted ? make_uint2((uint32_t)(base >> 6) | (fdir ? kFragDir : 0u) | kFragValid, clen) : make_uint2(0u, 0u);
                     // FragmentsInROI: first ROI (by end) whose end >= fragment end; counted if it contains the fragment.  The
                     // record is requested here and looked at below
-                    extent_ok[j] = n_roi_dev != 0u && counted && fs[j] <= fe[j] && fe[j] <= clen;
+                    extent_ok[j] = n_roi_dev != 0u && in_chr_count && fs[j] <= fe[j] && fe[j] <= clen;       // (FragmentsInROI, like FragmentsInChr, belongs to the owner of the fragment's start)
                     gfs[j] = base + fs[j]; gfe[j] = base + fe[j];
                     R[j] = roi_bkt[extent_ok[j] ? gfe[j] >> kBucketShift : 0ull];
                     // FragmentsInChr: one LDS atomic per distinct (chromosome, strand) of the wave
-                    const uint32_t k = counted ? chr[j] * 2u + fdir : kEmpty;
+                    const uint32_t k = in_chr_count ? chr[j] * 2u + fdir : kEmpty;
                     uint64_t todo = __ballot(k != kEmpty);
                     while (todo) {
                         const int lead = __ffsll((long long)todo) - 1;
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
 __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T) {
     __shared__ unsigned long long s_votes[2];
     if (threadIdx.x < 2u) s_votes[threadIdx.x] = 0ull;
-    __syncthreads();
+    wg_barrier();
     unsigned long long same = 0, opp = 0;
     // (a fixed grid that walks the table: the vote leaves as two atomics per workgroup, not two per wave on one address)
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < T.n_known; i += gridDim.x * 256u) {
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(256) void known_junction_depth_kernel(CountTables T
         if (same) atomicAdd(&s_votes[0], same);
         if (opp) atomicAdd(&s_votes[1], opp);
     }
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x < 2u && s_votes[threadIdx.x]) atomicAdd(&T.dir_votes[threadIdx.x], s_votes[threadIdx.x]);
 }
 

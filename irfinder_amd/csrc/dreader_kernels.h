@@ -4,6 +4,7 @@
 // fragment batch happens in HBM.  Every launcher is asynchronous on the given stream.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wg_barrier.h"
 
 #include <cstdint>
 

@@ -116,6 +116,11 @@ struct irf_ctx {
     std::vector<std::string> slot_names;         // BAM references, then reference-only names (sorted)
     std::vector<uint32_t> chr_len;
     std::vector<uint8_t> chr_owned;
+    // an owned reference may be owned in part: features (by their start / left / position) and FragmentsInChr (by the
+    // fragment's start) inside [own_start, own_end) are this context's; irf_chr_map_update_ranges, DESIGN.md §6
+    std::vector<uint32_t> own_start, own_end;
+    bool any_split = false;
+    bool in_own(uint32_t sl, uint32_t pos) const { return pos >= own_start[sl] && pos < own_end[sl]; }
     std::vector<uint64_t> chr_base;              // per BAM reference, offset inside a plane
     std::vector<uint32_t> refchr_slot;           // reference chr id -> slot
     uint64_t plane_stride = 0;                   // positions per strand plane (compact unless keep_depth)
@@ -157,6 +162,7 @@ struct irf_ctx {
     DevBuf<uint64_t> d_chr_base;
     DevBuf<uint32_t> d_chr_len;
     DevBuf<uint8_t> d_chr_owned;
+    DevBuf<uint2> d_chr_own;                     // [n_chr] own_start, own_end (read by the count kernel for references owned in part)
     DevBuf<uint32_t> d_chr_cnt;
     DevBuf<uint32_t> d_roi_idx, d_roi_cnt;
     DevBuf<uint4> d_roi_bkt;                     // kernels.h: CountTables::roi_bkt
@@ -253,7 +259,7 @@ struct irf_ctx {
 
     int init();
     void free_events();
-    int build_map(uint32_t n, const char* const* names, const uint32_t* lens, const uint8_t* owned);
+    int build_map(uint32_t n, const char* const* names, const uint32_t* lens, const uint8_t* owned, const uint32_t* r_start, const uint32_t* r_end);
     int zero_counters();
     dev::CountTables count_tables();
     int ensure_junc_capacity(uint64_t need);
@@ -374,7 +380,7 @@ void irf_ctx::free_events() {
 
 // Replaces ChrMapUpdate of all processors: binds reference-table chromosomes to
 // BAM refIDs and lays every table out in device order.
-int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* lens, const uint8_t* owned) {
+int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* lens, const uint8_t* owned, const uint32_t* r_start, const uint32_t* r_end) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipStreamSynchronize(copy_stream));
@@ -388,6 +394,16 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     chr_len.assign(lens, lens + n);
     chr_owned.assign(n, 1);
     if (owned) chr_owned.assign(owned, owned + n);
+    own_start.assign(n, 0u);
+    own_end.assign(n, 0xffffffffu);
+    any_split = false;
+    for (uint32_t i = 0; i < n && r_start && r_end; i++) {
+        if (!chr_owned[i]) continue;
+        if (r_start[i] >= r_end[i]) return fail(IRF_E_ARG, "irf_chr_map_update_ranges: empty or reversed range of an owned reference");
+        own_start[i] = r_start[i];
+        own_end[i] = r_end[i] > lens[i] ? 0xffffffffu : r_end[i];        // (an end beyond the reference = to its end)
+        if (own_start[i] != 0u || own_end[i] != 0xffffffffu) any_split = true;
+    }
     std::map<std::string, uint32_t> slot_of;
     for (uint32_t i = 0; i < n; i++) {
         slot_names.emplace_back(names[i]);
@@ -416,7 +432,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     std::vector<uint8_t> in_valid(n_intron);
     for (uint32_t i = 0; i < n_intron; i++) {
         uint32_t sl = refchr_slot[ref.in_chr[i]];
-        bool ok = sl < n && chr_owned[sl] && ref.in_end[i] <= chr_len[sl] && ref.in_start[i] <= ref.in_end[i];
+        bool ok = sl < n && chr_owned[sl] && in_own(sl, ref.in_start[i]) && ref.in_end[i] <= chr_len[sl] && ref.in_start[i] <= ref.in_end[i];
         for (uint32_t b = ref.in_blk_off[i]; ok && b < ref.in_blk_off[i + 1]; b++)
             if (ref.blk_end[b] > chr_len[sl] || ref.blk_end[b] < ref.blk_start[b]) ok = false;
         in_valid[i] = ok;
@@ -456,8 +472,12 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
     TRY(upload(this, d_chr_owned, chr_owned));
     {
         std::vector<uint4> rec(std::max<uint32_t>(n, 1u), make_uint4(0u, 0u, 0u, 0u));
-        for (uint32_t i = 0; i < n; i++) rec[i] = make_uint4((uint32_t)chr_base[i], (uint32_t)(chr_base[i] >> 32), chr_len[i], chr_owned[i] ? 1u : 0u);
+        for (uint32_t i = 0; i < n; i++) rec[i] = make_uint4((uint32_t)chr_base[i], (uint32_t)(chr_base[i] >> 32), chr_len[i],
+                                                             !chr_owned[i] ? 0u : ((own_start[i] != 0u || own_end[i] != 0xffffffffu) ? 2u : 1u));
         TRY(upload(this, d_chr_rec, rec));
+        std::vector<uint2> own(std::max<uint32_t>(n, 1u), make_uint2(0u, 0xffffffffu));
+        for (uint32_t i = 0; i < n; i++) own[i] = make_uint2(own_start[i], own_end[i]);
+        TRY(upload(this, d_chr_own, own));
     }
     {
         if (clear_stream) HIP_TRY(hipStreamSynchronize(clear_stream));
@@ -525,7 +545,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             sp_slot[i] = (uint32_t)(key[i] >> 32);
             sp_pos_sorted[i] = (uint32_t)key[i];
             const uint32_t sl = sp_slot[i];
-            if (sl < n && chr_owned[sl] && sp_pos_sorted[i] <= chr_len[sl]) { gpos.push_back(chr_base[sl] + sp_pos_sorted[i]); row.push_back(i); }
+            if (sl < n && chr_owned[sl] && in_own(sl, sp_pos_sorted[i]) && sp_pos_sorted[i] <= chr_len[sl]) { gpos.push_back(chr_base[sl] + sp_pos_sorted[i]); row.push_back(i); }
         }
         n_sp_dev = gpos.size();
         if (n_sp_dev >= 0xffffffffull) return fail(IRF_E_RANGE, "too many SpansPoint positions");
@@ -561,7 +581,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         for (uint32_t i : idx) {
             uint32_t sl = refchr_slot[ref.kj_chr[i]];
             kj_slot.push_back(sl); kj_left.push_back(ref.kj_left[i]); kj_right.push_back(ref.kj_right[i]); kj_dir.push_back(ref.kj_dir[i]);
-            if (sl < n && chr_owned[sl] && ref.kj_right[i] >= ref.kj_left[i]) {
+            if (sl < n && chr_owned[sl] && in_own(sl, ref.kj_left[i]) && ref.kj_right[i] >= ref.kj_left[i]) {
                 uint64_t span = (uint64_t)ref.kj_right[i] - ref.kj_left[i];
                 if (span < (1ull << dev::kJuncSpanBits)) {
                     kkeys.push_back(((chr_base[sl] + ref.kj_left[i]) << dev::kJuncSpanBits) | span);
@@ -731,11 +751,12 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
         std::vector<uint8_t> code(std::max<uint32_t>(n_intron, 1u), (uint8_t)dev::kRowOrphan);
         for (uint32_t i = 0; i < n_intron; i++) {
             const uint32_t sl = refchr_slot[ref.in_chr[i]];
-            if (sl < n) code[i] = chr_owned[sl] ? (uint8_t)dev::kRowMine : (uint8_t)dev::kRowForeign;
+            if (sl < n) code[i] = chr_owned[sl] && in_own(sl, ref.in_start[i]) ? (uint8_t)dev::kRowMine : (uint8_t)dev::kRowForeign;
         }
         TRY(upload(this, d_row_code, code));
         sharded = false;
         for (uint32_t i = 0; i < n; i++) if (!chr_owned[i]) sharded = true;
+        if (any_split) sharded = true;
     }
     {
         // every counter irf_reset zeroes (except the planes) in ONE allocation: one memset per sample instead of six
@@ -806,7 +827,7 @@ dev::CountTables irf_ctx::count_tables() {
     T.sp_min_len = P.sp_overhang_left + P.sp_overhang_right;
     T.plane_stride = plane_stride; T.pmap = pmap.empty() ? nullptr : d_pmap.p;
     T.junc_capacity = d_junc_a.cap;
-    T.chr_rec = d_chr_rec.p; T.cell_s = d_cell_s.p; T.cell_e = d_cell_e.p; T.jhash = d_jhash.p; T.jh_mask = jh_mask;
+    T.chr_rec = d_chr_rec.p; T.chr_own = d_chr_own.p; T.cell_s = d_cell_s.p; T.cell_e = d_cell_e.p; T.jhash = d_jhash.p; T.jh_mask = jh_mask;
     T.diff = d_diff.p; T.seg_sum = d_seg_sum.p; T.dirty = d_dirty.p; T.chr_cnt = d_chr_cnt.p;
     T.roi_bkt = d_roi_bkt.p; T.roi_gstart = d_roi_gstart.p; T.roi_gend = d_roi_gend.p; T.roi_idx = d_roi_idx.p;
     T.n_roi_dev = n_roi_dev; T.roi_cnt = d_roi_cnt.p;
@@ -1389,6 +1410,8 @@ int irf_ctx::export_col(uint32_t what_in, void* dst, uint64_t* n_out) {
         case IRF_COL_KNOWN_CNT: src = d_known_cnt.p; n = (uint64_t)n_kj * 2; break;
         default: return fail(IRF_E_ARG, "irf_export_device: unknown column");
     }
+    if (any_split && (what == IRF_COL_JUNC_KEYS || what == IRF_COL_JUNC_COUNTS))
+        return fail(IRF_E_STATE, "irf_export_device: a context that owns a reference in part hands its novel junctions out as coordinates (irf_export_junctions)");
     *n_out = n;
     if (!dst || !n) return 0;
     HIP_TRY(hipSetDevice(device));
@@ -1476,6 +1499,7 @@ int irf_ctx::own_novel_junctions(std::vector<ImpJunc>& out) {
         const uint32_t d = (uint32_t)(uk[u] & 1);
         while (chr + 1 < n_chr && (!chr_owned[chr] || gl >= chr_base[chr] + ((((uint64_t)chr_len[chr] + 1 + 63) / 64) * 64))) chr++;
         const uint32_t left = (uint32_t)(gl - chr_base[chr]);
+        if (!in_own(chr, left)) continue;       // a reference owned in part: the junction belongs to the context that owns its left end
         if (!out.empty() && out.back().chr == chr && out.back().left == left && out.back().right == left + span) {
             (d ? out.back().c1 : out.back().c0) += uc[u];
         } else {
@@ -1590,7 +1614,19 @@ int irf_chr_map_update(irf_ctx* c, uint32_t n_chr, const char* const* names, con
         if (!names[i]) return c->fail(IRF_E_ARG, "null chromosome name");
         if (lens[i] > 0x7fffffffu) return c->fail(IRF_E_RANGE, "reference length beyond 2^31-1");
     }
-    return c->build_map(n_chr, names, lens, owned);
+    return c->build_map(n_chr, names, lens, owned, nullptr, nullptr);
+}
+
+int irf_chr_map_update_ranges(irf_ctx* c, uint32_t n_chr, const char* const* names, const uint32_t* lens, const uint8_t* owned,
+                              const uint32_t* own_start, const uint32_t* own_end) {
+    if (!c) return IRF_E_ARG;
+    if (!names || !lens) return c->fail(IRF_E_ARG, "irf_chr_map_update_ranges needs names and lengths");
+    if ((own_start == nullptr) != (own_end == nullptr)) return c->fail(IRF_E_ARG, "irf_chr_map_update_ranges: own_start and own_end come together");
+    for (uint32_t i = 0; i < n_chr; i++) {
+        if (!names[i]) return c->fail(IRF_E_ARG, "null chromosome name");
+        if (lens[i] > 0x7fffffffu) return c->fail(IRF_E_RANGE, "reference length beyond 2^31-1");
+    }
+    return c->build_map(n_chr, names, lens, owned, own_start, own_end);
 }
 
 int irf_submit_batch(irf_ctx* c, const irf_batch* b, uint64_t* id) { return c ? c->submit(b, id) : IRF_E_ARG; }
@@ -1741,7 +1777,8 @@ int irf_gather(irf_ctx* const* ctxs, uint32_t n, uint32_t root) {
             return R->fail(IRF_E_ARG, "irf_gather: contexts with different reference tables or chromosome maps");
         for (uint32_t k = 0; k < c->n_chr; k++)
             for (uint32_t j = 0; j < i; j++)
-                if (c->chr_owned[k] && ctxs[j]->chr_owned[k]) return R->fail(IRF_E_ARG, "irf_gather: a BAM reference is owned by two contexts");
+                if (c->chr_owned[k] && ctxs[j]->chr_owned[k] && c->own_start[k] < ctxs[j]->own_end[k] && ctxs[j]->own_start[k] < c->own_end[k])
+                    return R->fail(IRF_E_ARG, "irf_gather: a BAM reference (or a part of it) is owned by two contexts");
     }
     // JunctionCount::Directional() over all shards
     unsigned long long same = 0, opp = 0;

@@ -3,6 +3,7 @@
 // pointers; every launcher is asynchronous on the given stream.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wg_barrier.h"
 
 #include <cstdint>
 
@@ -69,7 +70,8 @@ struct CountTables {
     uint32_t pad0;
     uint64_t plane_stride;     // elements per strand plane of the difference array (compact coordinates)
     uint64_t junc_capacity;
-    const uint4* chr_rec;      // [n_chr] x, y = offset of the chromosome in the full coordinate space, z = length, w = owned
+    const uint4* chr_rec;      // [n_chr] x, y = offset of the chromosome in the full coordinate space, z = length, w = 0 not owned, 1 owned, 2 owned in part
+    const uint2* chr_own;      // [n_chr] for w = 2: fragments that do not overlap [x, y) are ignored, FragmentsInChr counts the starts inside it
     const uint4* cell_s;       // [(full_size >> 5) + 2] asked with block starts (see above)
     const uint4* cell_e;       // ... with block ends
     // known junctions (ref-sj.ref) on owned chromosomes, open addressing (linear probing, load <= 1/32) on

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kThreads) void key_bits_kernel(const uint64_t* __re
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { o |= __shfl_xor(o, d); a &= __shfl_xor(a, d); }
     if ((threadIdx.x & 63) == 0) { s_o[threadIdx.x >> 6] = o; s_a[threadIdx.x >> 6] = a; }
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) {          // one pair of atomics per workgroup (they all hit the same two words)
         for (int w = 1; w < kWaves; w++) { o |= s_o[w]; a &= s_a[w]; }
         atomicOr(&out[0], o); atomicAnd(&out[1], a);
@@ -48,14 +48,14 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint64_t* __
                                                               uint32_t n_tiles, uint32_t* __restrict__ cnt) {
     __shared__ uint32_t s_h[256];
     s_h[threadIdx.x] = 0;
-    __syncthreads();
+    wg_barrier();
     const uint64_t tile0 = (uint64_t)blockIdx.x * kRadixTile;
 #pragma unroll
     for (int j = 0; j < kKeysPerThread; j++) {
         const uint64_t i = tile0 + (uint64_t)j * kThreads + threadIdx.x;
         if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
     }
-    __syncthreads();
+    wg_barrier();
     cnt[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];
 }
 
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
                                                                  const uint32_t* __restrict__ off) {
     __shared__ uint32_t s_cnt[kWaves][256];
     for (int k = threadIdx.x; k < kWaves * 256; k += kThreads) (&s_cnt[0][0])[k] = 0;
-    __syncthreads();
+    wg_barrier();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
     const uint64_t base = (uint64_t)blockIdx.x * kRadixTile + (uint64_t)wave * kWaveChunk + lane;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
             if ((peers & lane_lt) == 0ull) s_cnt[wave][d] = old + (uint32_t)__popcll(peers);
         }
     }
-    __syncthreads();
+    wg_barrier();
     {   // digit = threadIdx.x: turn the per-wave counts into global start offsets
         uint32_t run = off[(uint64_t)threadIdx.x * n_tiles + blockIdx.x];
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(const uint64_t*
             run += c;
         }
     }
-    __syncthreads();
+    wg_barrier();
 #pragma unroll
     for (int it = 0; it < kKeysPerThread; it++) {
         const uint64_t i = base + (uint64_t)it * 64u;

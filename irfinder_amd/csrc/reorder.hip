@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void reorder_keys_kernel(BatchDev B, cons
     const uint32_t last = (B.n_frag - i0 < (uint32_t)kThreads ? B.n_frag - i0 : (uint32_t)kThreads) - 1u;
     if (tid == 0u) s_range[0] = o0 < B.n_blk ? o0 : B.n_blk;
     if (tid == last) s_range[1] = o1 < B.n_blk ? o1 : B.n_blk;
-    __syncthreads();
+    wg_barrier();
     const uint32_t wb0 = s_range[0], wb1 = s_range[1];
     const bool staged = wb1 >= wb0 && wb1 - wb0 <= kStageBlocks;
     if (staged) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void reorder_keys_kernel(BatchDev B, cons
             s_blk[k - wb0] = make_uint2(B.blk_start[k], (len & ((1u << kReadShift) - 1u)) | ((rd & 3u) << kReadShift));
         }
     }
-    __syncthreads();
+    wg_barrier();
     uint2 blk[kInline];
 #pragma unroll
     for (uint32_t k = 0; k < kInline; k++) blk[k] = make_uint2(0u, 0u);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void reorder_keys_kernel(BatchDev B, cons
     s_rec[tid * 4u + 1u] = make_uint4(nb, o0, blk[0].x, blk[0].y);
     s_rec[tid * 4u + 2u] = make_uint4(blk[1].x, blk[1].y, blk[2].x, blk[2].y);
     s_rec[tid * 4u + 3u] = make_uint4(blk[3].x, blk[3].y, blk[4].x, blk[4].y);
-    __syncthreads();
+    wg_barrier();
     uint4* dst = reinterpret_cast<uint4*>(recs + i0);
     const uint32_t n16 = (last + 1u) * 4u;
 #pragma unroll

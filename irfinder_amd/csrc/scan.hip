@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void reduce_tiles_kernel(const uint32_t* 
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void scan_tiles_kernel(const uint32_t* in
         incl[r] = wave_inclusive_scan(v[r].x + v[r].y + v[r].z + v[r].w, lane);
         if (lane == 63) s_tot[r][wave] = incl[r];
     }
-    __syncthreads();
+    wg_barrier();
     const uint32_t base = tile_offset ? tile_offset[blockIdx.x] : 0u;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {

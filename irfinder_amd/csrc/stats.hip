@@ -260,14 +260,14 @@ __device__ __forceinline__ void block_excl_scan(uint32_t tot, unsigned long long
         return;
     }
     if (lane == 63) { s_wc[wave] = c; s_ws[wave] = s; }
-    __syncthreads();
+    wg_barrier();
     uint32_t bc = 0;
     unsigned long long bs = 0;
     for (int w = 0; w < kWaves; w++)
         if (w < (int)wave) { bc += s_wc[w]; bs += s_ws[w]; }
     pre = bc + c - tot;
     pre_sum = bs + s - tsum;
-    __syncthreads();
+    wg_barrier();
 }
 
 // The two ranks (0-based) the p-th percentile of n sorted values reads (OQ-7 formula), and its value from them.
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
     if (tid == 0) { s_max = 0; s_total = 0; s_nz = 0; s_acc = 0; }
     if (tid < 4) s_med[tid] = 0;
     if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
-    __syncthreads();
+    wg_barrier();
     PROF_MARK(0);
 
     // ---------------- pass A: histogram (clipped) + window capture ----------------
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             nwin[wi] = n;
         }
     }
-    __syncthreads();
+    wg_barrier();
     PROF_MARK(2);
     // ---------------- per table: medians, rank queries, the row ----------------
 #pragma unroll
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
         if (tid == 0) { s_max = 0; s_total = 0; s_nz = 0; s_acc = 0; }
         if (tid < 4) s_med[tid] = 0;
         if (tid < kQueries) { s_qval[tid] = 0; s_qsum[tid] = 0; }
-        __syncthreads();
+        wg_barrier();
     }
     uint32_t* const cnt = s_cnt + t * kBins;
     const int plane = planes[t];
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             }
         }
         if (lt) reinterpret_cast<uint4*>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
+        wg_barrier();
     } else if (N > 0 && !overflow) {
         // single level: bins are the depths themselves
         uint32_t c[kBinsPerThread];
@@ -753,10 +753,10 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
 #pragma unroll
             for (int j = 0; j < kBinsPerThread; j++) cnt[tid * kBinsPerThread + j] = 0;
         }
-        __syncthreads();
+        wg_barrier();
     } else if (N > 0) {
         // multi-level radix select, one descent per query; a sum query (q < 2) then adds the values below the selected one
-        __syncthreads();
+        wg_barrier();
         int bits = 32 - __clz((int)s_max);
         int levels = (bits + kBinBits - 1) / kBinBits;
         if (levels < 1) levels = 1;
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
             for (int lv = 0; lv < levels; lv++) {
                 const int shift = kBinBits * (levels - 1 - lv);
                 for (int k = tid; k < kBins; k += kThreads) cnt[k] = 0;
-                __syncthreads();
+                wg_barrier();
                 for (uint32_t b = b0; b < b0 + nb; b++) {
                     const uint64_t bc = blks[b].cstart;
                     for_each_depth<kWaves>(C, bc, bc + blks[b].len, [&](uint64_t, uint32_t v, bool ok) {
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
                         if (in) atomicAdd(&cnt[(v >> shift) & (uint32_t)(kBins - 1)], 1u);
                     });
                 }
-                __syncthreads();
+                wg_barrier();
                 uint32_t c[kBinsPerThread];
                 uint32_t tot = 0;
 #pragma unroll
@@ -794,10 +794,10 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
                         run += c[j];
                     }
                 }
-                __syncthreads();
+                wg_barrier();
                 prefix = (prefix << kBinBits) | s_sel_bin;
                 r -= s_sel_cnt;
-                __syncthreads();
+                wg_barrier();
             }
             // prefix = the value at the rank; r = the rank's position among the copies of that value
             unsigned long long below = 0;
@@ -812,17 +812,17 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
                 if (lane == 0 && part) atomicAdd(&s_acc, part);
-                __syncthreads();
+                wg_barrier();
                 below = s_acc;
-                __syncthreads();
+                wg_barrier();
                 if (tid == 0) s_acc = 0;
             }
             if (tid == 0) { s_qval[q] = prefix; s_qsum[q] = below + (unsigned long long)prefix * r; }
         }
         for (int k = tid; k < kBins; k += kThreads) cnt[k] = 0;            // (the histograms are zero between introns)
-        __syncthreads();
+        wg_barrier();
     } else {
-        __syncthreads();
+        wg_barrier();
     }
     PROF_MARK(4);
 
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(kThreads, (kTables == 2 ? STATS_MIN_WAVES_DUAL : ST
         out_u32[4 * n + i] = je;
         out_u32[5 * n + i] = warn;
     }
-    __syncthreads();            // the row has read the LDS results: the next table / intron may clear them
+    wg_barrier();            // the row has read the LDS results: the next table / intron may clear them
     }       // tables
     PROF_MARK(5);
     recA = recB; recB = recC; dA = dB; tcA = tcB;

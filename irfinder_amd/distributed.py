@@ -31,6 +31,72 @@ def shard_chromosomes(weights, world):
     return masks
 
 
+def feature_intervals(ref_texts, chr_name):
+    """[start, end] of the introns, ref-sj junctions and read-continues points of one chromosome: a reference may be cut
+    only outside all of them (ROIs may span a cut: ref-ROI.bed lists the intergenic regions themselves, and FragmentsInROI
+    is counted by the owner of the fragment's start)."""
+    cover, sj, rc, roi = ref_texts
+    iv = []
+    for text, a, b in ((cover, 1, 2), (sj, 1, 2)):
+        for line in text.splitlines():
+            f = line.split("\t")
+            if len(f) > b and f[0] == chr_name:
+                iv.append((int(f[a]), int(f[b])))
+    for line in rc.splitlines():
+        f = line.split("\t")
+        if len(f) > 1 and f[0] == chr_name:
+            iv.append((int(f[1]), int(f[1])))
+    return iv
+
+
+def intergenic_cut(ref_texts, chr_name, chr_len, target, margin=1000):
+    """The position nearest to `target` that no feature of the reference files spans or touches (with `margin` bases of
+    room on both sides: reads of the neighbouring features end well before it), or None if the chromosome has no such
+    gap.  This is where irf_chr_map_update_ranges may cut the reference between two contexts."""
+    iv = sorted(feature_intervals(ref_texts, chr_name))
+    gaps, at = [], 0
+    for a, b in iv:
+        if a - margin > at + margin:
+            gaps.append((at + margin, a - margin))
+        at = max(at, b + 1)
+    if chr_len - margin > at + margin:
+        gaps.append((at + margin, chr_len - margin))
+    best = None
+    for a, b in gaps:
+        c = min(max(int(target), a), b)
+        if best is None or abs(c - target) < abs(best - target):
+            best = c
+    return best
+
+
+def shard_with_split(weights, chr_lens, world, ref_texts, chr_names, weight_left_of=None):
+    """shard_chromosomes, then the heaviest reference is cut in two at an intergenic gap when it alone weighs more than
+    the mean load of a rank (a sample where one reference exceeds 1/N of the reads; SURVEY §8 e): its right part goes to
+    the lightest rank.  weight_left_of(chr, pos) -> fraction of the reference's weight left of pos (default: pos / len).
+    Returns (masks, own_start, own_end): per rank an uint8 mask and uint32 arrays for irf_chr_map_update_ranges."""
+    w = np.asarray(weights, dtype=np.float64)
+    masks = shard_chromosomes(w, world)
+    n = len(w)
+    starts = [np.zeros(n, np.uint32) for _ in range(world)]
+    ends = [np.full(n, 0xffffffff, np.uint32) for _ in range(world)]
+    heavy = int(np.argmax(w))
+    if world < 2 or w[heavy] <= w.sum() / world:
+        return masks, starts, ends
+    owner = next(r for r in range(world) if masks[r][heavy])
+    loads = np.array([float(np.dot(m, w)) for m in masks])
+    other = int(np.argmin(np.where(np.arange(world) == owner, np.inf, loads)))
+    # the owner keeps the left part up to where both ranks carry the same load
+    keep = (loads[other] + w[heavy] - (loads[owner] - w[heavy])) / (2.0 * w[heavy])
+    keep = min(max(keep, 0.05), 0.95)
+    cut = intergenic_cut(ref_texts, chr_names[heavy], int(chr_lens[heavy]), keep * int(chr_lens[heavy]))
+    if cut is None:
+        return masks, starts, ends
+    ends[owner][heavy] = cut
+    masks[other][heavy] = 1
+    starts[other][heavy] = cut
+    return masks, starts, ends
+
+
 def plane_bases(chr_lens, owned):
     """chr_base[] exactly as the engine lays out the depth planes of a rank (owned references only, len+1 rounded
     up to 64) — needed to decode that rank's packed junction keys."""

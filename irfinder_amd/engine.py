@@ -67,6 +67,7 @@ def lib():
     L.irf_last_error.argtypes = [vp]
     L.irf_last_error.restype = C.c_char_p
     L.irf_chr_map_update.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32), C.c_void_p]
+    L.irf_chr_map_update_ranges.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32), C.c_void_p, C.c_void_p, C.c_void_p]
     L.irf_submit_batch.argtypes = [vp, C.POINTER(IrfBatch), C.POINTER(u64)]
     L.irf_wait.argtypes = [vp, u64]
     L.irf_finalize.argtypes = [vp]
@@ -394,7 +395,9 @@ class Engine:
         if rc != 0:
             raise IrfError(rc, self.L.irf_last_error(self.h).decode())
 
-    def chr_map_update(self, names, lens, owned=None):
+    def chr_map_update(self, names, lens, owned=None, own_start=None, own_end=None):
+        """owned: 0/1 per BAM reference; own_start / own_end: the part [start, end) of every owned reference this context
+        owns (irf_chr_map_update_ranges; None = whole references)."""
         n = len(names)
         arr = (C.c_char_p * n)(*[s.encode() for s in names])
         la = (C.c_uint32 * n)(*[int(x) for x in lens])
@@ -402,7 +405,12 @@ class Engine:
         if owned is not None:
             self._owned = np.ascontiguousarray(owned, np.uint8)
             ow = self._owned.ctypes.data
-        self._chk(self.L.irf_chr_map_update(self.h, n, arr, la, ow))
+        if own_start is None and own_end is None:
+            self._chk(self.L.irf_chr_map_update(self.h, n, arr, la, ow))
+            return
+        self._own = (np.ascontiguousarray(own_start, np.uint32), np.ascontiguousarray(own_end, np.uint32))
+        assert len(self._own[0]) == n and len(self._own[1]) == n
+        self._chk(self.L.irf_chr_map_update_ranges(self.h, n, arr, la, ow, self._own[0].ctypes.data, self._own[1].ctypes.data))
 
     def submit(self, batch):
         """batch: _abi.Batch (host) or an IrfBatch struct (host or device pointers)."""

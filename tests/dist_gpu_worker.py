@@ -33,10 +33,14 @@ def main():
     w = pickle.load(open(world_pkl, "rb"))
     refs, names, lens, batch = w["refs"], w["names"], w["lens"], w["batch"]
     weights = np.bincount(batch.frag_chr, minlength=len(names))          # what a BAI's mapped-read counts give
-    masks = irfdist.shard_chromosomes(weights, world)
     dev = torch.device("cuda", 0)
     eng = engine.Engine(engine.RefTables.from_texts(refs), device=0)
-    eng.chr_map_update(names, lens, masks[rank])
+    if "split" in w:          # a reference cut at an intergenic gap (distributed.shard_with_split; irf_chr_map_update_ranges)
+        masks, starts, ends = w["split"]
+        eng.chr_map_update(names, lens, masks[rank], starts[rank], ends[rank])
+    else:
+        masks = irfdist.shard_chromosomes(weights, world)
+        eng.chr_map_update(names, lens, masks[rank])
     eng.process(batch)                                                   # foreign fragments are ignored by the engine
     eng.finalize()
     v = torch.tensor(eng.votes(), dtype=torch.int64)

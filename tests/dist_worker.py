@@ -19,12 +19,13 @@ sys.path.insert(0, HERE)
 import orc  # noqa: E402
 from irfinder_amd import distributed as irfdist  # noqa: E402
 from irfinder_amd import engine  # noqa: E402
-from util import small_world  # noqa: E402
+from util import small_world, split_case  # noqa: E402
 
 
 def main():
     out_path = sys.argv[1]
     stranded = bool(int(sys.argv[2]))
+    split = len(sys.argv) > 3 and bool(int(sys.argv[3]))       # reference 0 cut at an intergenic gap (shard_with_split)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     ann, sim = small_world(seed=17, stranded=stranded, n_chr=5)
@@ -33,18 +34,37 @@ def main():
     rd.finish()
     names, lens = rd.header()
     batch = rd.take_batch()
-    masks = irfdist.shard_chromosomes(lens, world)
-    owned = masks[rank]
-    mine = batch.select(np.nonzero(owned[batch.frag_chr] == 1)[0])
+    if split:
+        masks, starts, ends, batch, _ = split_case(ann, names, lens, batch, world)
+    else:
+        masks = irfdist.shard_chromosomes(lens, world)
+        starts = [np.zeros(len(lens), np.uint32) for _ in range(world)]
+        ends = [np.full(len(lens), 0xffffffff, np.uint32) for _ in range(world)]
+    owned, lo, hi = masks[rank], starts[rank].astype(np.int64), ends[rank].astype(np.int64)
+
+    def in_own(chr_ids, pos):       # the rule of irf_chr_map_update_ranges: a feature belongs to the owner of its start
+        chr_ids, pos = np.asarray(chr_ids, np.int64), np.asarray(pos, np.int64)
+        return (owned[chr_ids] == 1) & (pos >= lo[chr_ids]) & (pos < hi[chr_ids])
+
+    fc, fs, fe = batch.frag_chr.astype(np.int64), batch.frag_start.astype(np.int64), batch.frag_end.astype(np.int64)
+    # counted whole: every fragment that reaches into this rank's part of its reference
+    mine = batch.select(np.nonzero((owned[fc] == 1) & (fs < hi[fc]) & (fe > lo[fc]))[0])
     o = orc.Oracle(ann.ref_texts())
     o.chr_map_update(names, lens)
     o.process_batch(mine)
     o.finalize()
     r = o.results()
+    # FragmentsInChr / FragmentsInROI: a fragment belongs to the owner of its start
+    o2 = orc.Oracle(ann.ref_texts())
+    o2.chr_map_update(names, lens)
+    o2.process_batch(batch.select(np.nonzero(in_own(fc, fs))[0]))
+    o2.finalize()
+    r2 = o2.results()
     n_in = r["n_intron"]
     name_to_idx = {n: i for i, n in enumerate(names)}
-    in_chr = np.array([name_to_idx[l.split("\t", 1)[0]] for l in ann.cover_bed.splitlines()], np.int64)
-    intron_owned = torch.from_numpy(owned[in_chr].astype(np.int64))
+    cover = [l.split("\t") for l in ann.cover_bed.splitlines()]
+    in_chr = np.array([name_to_idx[f[0]] for f in cover], np.int64)
+    intron_owned = torch.from_numpy(in_own(in_chr, [int(f[1]) for f in cover]).astype(np.int64))
 
     def table(t):
         f = np.stack([t[k] for k in ("coverage", "intron_depth", "p25", "p50", "p75", "first50", "last50", "irratio")])
@@ -55,7 +75,8 @@ def main():
     f64, u32 = table(r["nondir"])
     irfdist.mask_unowned_rows(f64, u32, intron_owned)
     # observed junctions of this rank, packed with this rank's plane layout
-    obs = np.nonzero(r["junc_cnt"].sum(axis=0) > 0)[0]
+    obs = np.nonzero((r["junc_cnt"].sum(axis=0) > 0) & in_own(r["junc_chr"], r["junc_left"]))[0]        # a junction belongs to the owner of its left end
+    sp_mine = in_own(r["sp_chr"], r["sp_pos"]).astype(np.int32)
     base = irfdist.plane_bases(lens, owned)
     keys, cnts = [], []
     for j in obs:
@@ -69,9 +90,9 @@ def main():
     cnts = np.asarray(cnts, np.int32)[order]
     tabs = {
         "ir_f64": f64, "ir_u32": u32,
-        "sp_cnt": torch.from_numpy(r["sp_cnt"].astype(np.int32).ravel().copy()),
-        "roi_cnt": torch.from_numpy(r["roi_cnt"].astype(np.int32).ravel().copy()),
-        "chr_cnt": torch.from_numpy(r["chr_cnt"].astype(np.int32).ravel().copy()),
+        "sp_cnt": torch.from_numpy((r["sp_cnt"].astype(np.int32) * sp_mine[None, :]).ravel().copy()),
+        "roi_cnt": torch.from_numpy(r2["roi_cnt"].astype(np.int32).ravel().copy()),
+        "chr_cnt": torch.from_numpy(r2["chr_cnt"].astype(np.int32).ravel().copy()),
         "junc_keys": torch.from_numpy(keys.view(np.int64).copy()),
         "junc_counts": torch.from_numpy(cnts.copy()),
     }

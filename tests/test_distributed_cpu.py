@@ -11,7 +11,7 @@ import pytest
 import orc
 from irfinder_amd import distributed as irfdist
 from irfinder_amd import engine
-from util import small_world
+from util import small_world, split_case
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -46,13 +46,15 @@ def test_decode_junction_keys_roundtrip():
     assert list(zip(ch.tolist(), l.tolist(), r.tolist(), d.tolist())) == items
 
 
-@pytest.mark.parametrize("world,stranded", [(2, 0), (3, 1)])
-def test_gloo_sharded_run_equals_single_run(world, stranded, tmp_path):
+@pytest.mark.parametrize("world,stranded,split", [(2, 0, 0), (3, 1, 0), (2, 1, 1)])
+def test_gloo_sharded_run_equals_single_run(world, stranded, split, tmp_path):
+    """split = 1: reference 0 outweighs a rank's share and is cut at an intergenic gap (distributed.shard_with_split, the
+    ownership rules of irf_chr_map_update_ranges), with fragments lying across the cut."""
     out = tmp_path / "gathered.pkl"
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"), str(out), str(stranded)]
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"), str(out), str(stranded), str(split)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     got = pickle.load(open(out, "rb"))
@@ -63,6 +65,9 @@ def test_gloo_sharded_run_equals_single_run(world, stranded, tmp_path):
     rd.finish()
     names, lens = rd.header()
     batch = rd.take_batch()
+    if split:
+        masks, starts, ends, batch, cut = split_case(ann, names, lens, batch, world)
+        assert got["masks"][0][0] == 1 and got["masks"][1][0] == 1          # both ranks own a part of reference 0
     o = orc.Oracle(ann.ref_texts())
     o.chr_map_update(names, lens)
     o.process_batch(batch)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from irfinder_amd import engine
-from util import assert_results_equal, small_world
+from util import assert_results_equal, small_world, split_case
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,18 +26,24 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,stranded", [(2, True), (3, False)])
-def test_ranks_with_real_engines_equal_the_single_context_run(world, stranded, tmp_path):
+@pytest.mark.parametrize("world,stranded,split", [(2, True, False), (3, False, False), (2, True, True)])
+def test_ranks_with_real_engines_equal_the_single_context_run(world, stranded, split, tmp_path):
+    """split: reference 0 outweighs a rank's share and is cut at an intergenic gap between the two ranks (each rank is fed
+    the whole sample, fragments across the cut included)."""
     ann, sim = small_world(seed=29, stranded=stranded, n_chr=5)
     r = engine.Reader()
     r.feed(sim.bam(0, 30000))
     r.finish()
     names, lens = r.header()
     batch = r.take_batch()
+    extra = {}
+    if split:
+        masks, starts, ends, batch, cut = split_case(ann, names, lens, batch, world)
+        extra["split"] = (masks, starts, ends)
     sj = "".join(l for i, l in enumerate(ann.sj_ref.splitlines(True)) if i % 3)          # a third of the junctions are novel
     cover = ann.cover_bed + "chrNowhere\t10\t500\tQ/E/+/1/10/500/clean\t0\t+\t10\t500\t0\t1\t490\t0\n"
     refs = (cover, sj, ann.read_continues_ref, ann.roi_bed)
-    pickle.dump({"refs": refs, "names": names, "lens": lens, "batch": batch}, open(tmp_path / "world.pkl", "wb"))
+    pickle.dump(dict({"refs": refs, "names": names, "lens": lens, "batch": batch}, **extra), open(tmp_path / "world.pkl", "wb"))
     out = tmp_path / "gathered"
     os.makedirs(out)
     env = dict(os.environ, OMP_NUM_THREADS="1")

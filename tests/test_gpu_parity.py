@@ -474,6 +474,67 @@ def test_cli_dropin_direct_adapter_and_bgzf(tmp_path):
             assert filecmp.cmp(out / f, cpu / f, shallow=False), (tag, f)
 
 
+@pytest.mark.parametrize("order", [0, 1])
+def test_reference_split_at_an_intergenic_gap(order, tmp_path):
+    """irf_chr_map_update_ranges (SURVEY §8 e: a sample in which one reference outweighs 1/N of the reads): the heaviest
+    reference is cut at an intergenic gap, the two parts go to two contexts, each is fed the WHOLE sample — plus
+    hand-made fragments that lie across the cut: one covering it, one with a spliced read whose junction spans it (novel,
+    twice; and once more as a junction of ref-sj.ref) — and irf_gather must give the single-context tables and files."""
+    from irfinder_amd import distributed as irfdist
+    from irfinder_amd._abi import Batch as B_, IRF_FRAG_DIR, IRF_FRAG_TWO
+    from irfinder_amd.synth import world as synth_world
+    ann, sim = small_world(seed=29, stranded=True, n_chr=3)
+    names, lens, batch = read_batch(sim.bam(0, 30000))
+    w = np.asarray(lens, np.float64)
+    w[0] *= 4                                                  # chrT1 alone is heavier than a rank's fair share
+    texts = list(ann.ref_texts())
+    masks, starts, ends = irfdist.shard_with_split(w, lens, 2, texts, names)
+    cut = int(ends[0][0])
+    assert masks[0][0] == 1 and masks[1][0] == 1 and int(starts[1][0]) == cut and 0 < cut < lens[0]
+    # fragments across the cut (chrT1 is reference 0): a pair whose read 1 covers the cut; a single read spliced over it
+    # (left block ends 150 before the cut, right block starts 250 behind it), twice on the + strand and once on the -
+    span_l, span_r = cut - 150, cut + 250
+    extra = B_(frag_chr=[0, 0, 0, 0], frag_flags=[IRF_FRAG_DIR | IRF_FRAG_TWO, IRF_FRAG_DIR, IRF_FRAG_DIR, 0],
+               frag_start=[cut - 60, cut - 250, cut - 250, cut - 230], frag_end=[cut + 300, cut + 350, cut + 350, cut + 330],
+               frag_blk_off=[0, 2, 4, 6, 8],
+               blk_start=[cut - 60, cut + 200, cut - 250, span_r, cut - 250, span_r, cut - 230, span_r],
+               blk_len=[100, 100, 100, 100, 100, 100, 80, 80], blk_read=[0, 1, 0, 0, 0, 0, 0, 0])
+    whole_batch = synth_world.concat_batches([batch, extra])
+    for known in (False, True):
+        refs = list(texts)
+        if known:      # the junction across the cut is listed in ref-sj.ref: known for the owner of its left end, novel for the other context
+            refs[1] = refs[1] + "%s\t%d\t%d\t+\n" % (names[0], span_l, span_r)
+        e, whole = run_gpu(refs, names, lens, [whole_batch])
+        o, c = run_orc(refs, names, lens, [whole_batch])
+        assert_results_equal(whole, c, rel=0.0, what="single context vs oracle")
+        engs = []
+        for r in range(2):
+            ei = engine.Engine(engine.RefTables.from_texts(refs))
+            ei.chr_map_update(names, lens, masks[r], starts[r], ends[r])
+            ei.set_input_order(order)
+            ei.process(whole_batch)
+            ei.finalize()
+            engs.append(ei)
+        # each part alone: the chromosome counts of the two contexts add up, a fragment counted where it starts
+        parts = [x.results() for x in engs]
+        assert np.array_equal(parts[0]["chr_cnt"] + parts[1]["chr_cnt"], whole["chr_cnt"])
+        assert np.array_equal(parts[0]["roi_cnt"] + parts[1]["roi_cnt"], whole["roi_cnt"])
+        engine.gather(engs, root=0)
+        got = engs[0].results()
+        assert_results_equal(got, whole, rel=0.0, what="reference split at %d, junction across the cut %s" % (cut, "known" if known else "novel"))
+        j = np.nonzero((got["junc_left"] == span_l) & (got["junc_right"] == span_r))[0]
+        assert len(j) == 1 and got["junc_cnt"][:, j[0]].sum() == 3
+        out_a, out_b = tmp_path / ("whole%d" % known), tmp_path / ("split%d" % known)
+        os.makedirs(out_a); os.makedirs(out_b)
+        e.write_outputs(str(out_a)); engs[0].write_outputs(str(out_b))
+        for f in sorted(os.listdir(out_a)):
+            assert filecmp.cmp(out_a / f, out_b / f, shallow=False), f
+    # the packed junction columns of such a context are refused (their rows must be filtered by coordinate)
+    from irfinder_amd._abi import COL_JUNC_KEYS
+    with pytest.raises(engine.IrfError):
+        engs[1].export_size(COL_JUNC_KEYS)
+
+
 def test_rccl_collect_program_with_a_one_rank_communicator(tmp_path):
     """irfinder_amd/irf_rccl_collect (host/rccl_collect_main.cpp + rccl_collect.h: the C recipe of INTEGRATION.md §5,
     linked against librccl) as a fresh child process with a ONE-rank communicator: ncclCommInitRank, the all-reduce of

@@ -44,3 +44,25 @@ def assert_results_equal(a, b, rel=0.0, what=""):
                                                                                 ta[k][bad].tolist(), tb[k][bad].tolist()))
     for k in ("n_fragments", "n_blocks", "n_junction_events"):
         assert a[k] == b[k], (what, k, a[k], b[k])
+
+
+def split_case(ann, names, lens, batch, world=2):
+    """A sample in which reference 0 outweighs a rank's fair share: shard_with_split cuts it at an intergenic gap.
+    Returns (masks, own_start, own_end, batch + four hand-made fragments that lie across the cut: a pair whose read 1
+    covers it and three single reads spliced over it)."""
+    import numpy as np
+    from irfinder_amd import distributed as irfdist
+    from irfinder_amd._abi import Batch, IRF_FRAG_DIR, IRF_FRAG_TWO
+    from irfinder_amd.synth import world as synth_world
+    w = np.asarray(lens, np.float64)
+    w[0] *= 2 * len(lens)          # (heavier than a fair share whatever the number of references)
+    masks, starts, ends = irfdist.shard_with_split(w, lens, world, list(ann.ref_texts()), names)
+    cut = int(ends[[r for r in range(world) if masks[r][0] and int(starts[r][0]) == 0][0]][0])
+    assert 300 < cut < lens[0] - 400
+    span_r = cut + 250
+    extra = Batch(frag_chr=[0, 0, 0, 0], frag_flags=[IRF_FRAG_DIR | IRF_FRAG_TWO, IRF_FRAG_DIR, IRF_FRAG_DIR, 0],
+                  frag_start=[cut - 60, cut - 250, cut - 250, cut - 230], frag_end=[cut + 300, cut + 350, cut + 350, cut + 330],
+                  frag_blk_off=[0, 2, 4, 6, 8],
+                  blk_start=[cut - 60, cut + 200, cut - 250, span_r, cut - 250, span_r, cut - 230, span_r],
+                  blk_len=[100, 100, 100, 100, 100, 100, 80, 80], blk_read=[0, 1, 0, 0, 0, 0, 0, 0])
+    return masks, starts, ends, synth_world.concat_batches([batch, extra]), cut
