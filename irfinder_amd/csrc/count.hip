@@ -721,6 +721,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
             for (uint32_t t0 = kb0; t0 < kb1;) {
                 const uint32_t tile_n = kb1 - t0 < kTile ? kb1 - t0 : kTile;
                 const uint32_t n_str = (tile_n + kStride - 1u) / kStride;
+                // (The first stride's columns were requested in the fragment phase and have long arrived; the compiler does not
+                //  know — the wait behind the fragment phase is inline assembly — and, merging "still in flight" from the loop's
+                //  entry with the back edge, it waited for the NEXT stride's columns at the top of every iteration, a full
+                //  round trip in front of the table loads.  A use here makes it place its own wait in front of the loop.)
+#pragma unroll
+                for (int u = 0; u < kBU; u++) asm volatile("" : "+v"(nxt[u].bs), "+v"(nxt[u].bl), "+v"(nxt[u].rd));
                 for (uint32_t s0 = wave; s0 < n_str; s0 += kWaves * kBU) {
                     // (a stride beyond the tile's last does nothing: `here` is false in every lane)
                     Cols cur[kBU];
