@@ -169,6 +169,9 @@ struct Lds {
     uint32_t ll_n, jl_n, pl_n, rl_n;
     uint32_t wmax[2];                  // highest window offset + 1 a chunk touched
     uint32_t nq_n, nh_n, oq_n[2], oq_cur;   // oq_cur: the queue the block phase fills (the flush drains the other one)
+    // the slice's chunks: window origin of each, first block of each (and of the chunk behind the last); read once per slice
+    unsigned long long s_org[kSlice];
+    uint32_t s_kb[kSlice + 1];
 };
 
 // Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
@@ -557,6 +560,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
         const uint32_t c0 = slice * kSlice;
         const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
         FragCols fc_next = load_frag(c0);
+        // (two dependent round trips per chunk otherwise: the origin decides what the flush does, the block range where the
+        //  first strides' columns are.  Nobody reads these words between the last barrier of a slice and the first of the next.)
+        if (tid < kSlice) S.s_org[tid] = tid < nc ? origin[c0 + tid] : kNoWin;
+        if (tid >= 64u && tid - 64u <= kSlice) {
+            const unsigned long long f = (unsigned long long)(c0 + tid - 64u) * kChunk;
+            S.s_kb[tid - 64u] = B.frag_blk_off[f < B.n_frag ? (uint32_t)f : B.n_frag];
+        }
         unsigned long long win = 0;     // window = plane positions [win, win + kWin); uniform over the workgroup, like the next three
         uint32_t wtop = 0;              // cells of win + [0, wtop) may be non-zero
         uint32_t ev_since = 0;          // upper bound of the events added since everything was last flushed
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
             // (the queue chunk i - 1 filled; a slice begins with both queues drained, whatever their counts say)
             const uint32_t n_oq = i == 0u ? 0u : (S.oq_n[(i + 1u) & 1u] < kOQ ? S.oq_n[(i + 1u) & 1u] : kOQ);
             const unsigned long long win_old = win;
-            const unsigned long long nw = last ? kNoWin : origin[c0 + i];
+            const unsigned long long nw = last ? kNoWin : S.s_org[last ? 0u : i];
             if (tid == 0) { S.wmax[i & 1u] = 0; S.oq_n[i & 1u] = 0; S.oq_cur = i & 1u; }
             const bool ev_full = ev_since > kEvFlush;
             bool jump = false;
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
             if (!last) {
                 const uint32_t f0 = (c0 + i) * kChunk;
                 const uint32_t f_end = f0 + kChunk < B.n_frag ? f0 + kChunk : B.n_frag;
-                kb0 = B.frag_blk_off[f0]; kb1 = B.frag_blk_off[f_end];
+                kb0 = S.s_kb[i]; kb1 = S.s_kb[i + 1u];
                 kb0 = kb0 < B.n_blk ? kb0 : B.n_blk;
                 kb1 = kb1 < B.n_blk ? kb1 : B.n_blk;
                 if (kb1 < kb0) kb1 = kb0;
