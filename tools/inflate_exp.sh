@@ -9,4 +9,4 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DIRF_INFLATE_EX
 /opt/rocm/bin/hipcc $F "$@" -c bgzf.hip -o /tmp/bgzf_$mask.o
 /opt/rocm/bin/hipcc $F "$@" -c dreader.hip -o /tmp/dreader_$mask.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../tools/variants/libirfhip_inf$mask.so /tmp/bgzf_$mask.o /tmp/dreader_$mask.o \
-  count.o scan.o radix.o stats.o engine.o bamparse.o ref_tables.o bam_reader.o reader_abi.o writers.o -lz -pthread
+  count.o scan.o radix.o stats.o gather.o reorder.o engine.o bamparse.o ref_tables.o bam_reader.o reader_abi.o writers.o -lz -pthread
