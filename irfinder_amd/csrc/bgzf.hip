@@ -14,8 +14,9 @@
 // from registers; the code lengths are read TWICE (count per length, then place the symbols), which saves a 320-entry
 // per-lane length array.
 //
-// Output: literal bytes collect in a register and leave as aligned dwords; matches copy 4 bytes per round trip when
-// the distance allows.  The CRC-32 of every member is checked by a second kernel (one wave per member, 64 slices
+// Output: literal bytes collect in a register and leave as dwords; a match of up to 32 bytes is a deferred copy (loads
+// now, stores behind the next symbol's decode; one that overlaps its own output at a distance below 8 is stored as the
+// period the first 8 loaded bytes hold), anything else is copied in place.  The CRC-32 of every member is checked by a second kernel (one wave per member, 64 slices
 // combined with x^(8n) mod P), so a corrupt file is refused exactly where the host reader refuses it.
 #include "dreader_kernels.h"
 
@@ -25,7 +26,7 @@ namespace dev {
 namespace {
 
 #ifndef IRF_LITERAL_RUN
-#define IRF_LITERAL_RUN 1          // literals taken in the same iteration as the symbol before them (0 .. 2: the input window is four words)
+#define IRF_LITERAL_RUN 1          // a literal behind a symbol is taken in the same iteration (0 or 1: it refills from the OLD input window)
 #endif
 
 constexpr int LIT_SYM = 0, DIST_SYM = 288, LIT_LIM = 320, LIT_BASE = 335, DIST_LIM = 350, DIST_BASE = 365, TAB_U16 = 380;
@@ -62,20 +63,17 @@ struct Bits {
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
-// The bit buffer of the symbol loop: the next four input words (q0 .. q3 = the 16 bytes at p, nq of them still unused)
-// are in registers, so a refill is register work.  An iteration refills at most three times (15 + 5 bits, refill, 15 + 13
-// bits, refill, 15 bits of a literal pair, refill); at its bottom a lane with fewer than three words left reloads all four with ONE 16-byte load.  The load is
-// issued by every lane in every iteration (uniform instruction stream, see the kernel), but the lanes that do not need it
-// — about eight of nine — all read the same address: the cost of a vector memory instruction here is the number of
-// distinct cache lines it touches, not its width.
+// The bit buffer of the symbol loop: the next four input words (q0 .. q3 = the 16 bytes at p) are in registers, so a
+// refill is register work.  An iteration refills at most three times (15 + 5 bits, refill, 15 + 13 bits, refill, 15 bits
+// of the literal behind the symbol, refill) and every lane reloads all four words with ONE 16-byte load per iteration (its
+// own address: 64 cache lines per instruction, once per iteration).
 struct FastBits {
     const uint8_t* p;    // address of q0
     uint64_t bb;
-    uint32_t bc, q0, q1, q2, q3, nq;
+    uint32_t bc, q0, q1, q2, q3;
     __device__ __forceinline__ void from(const Bits& s) {
         p = s.p - 4; bb = s.bb; bc = s.bc; q0 = s.nxt;
         q1 = ld32u(s.p); q2 = ld32u(s.p + 4); q3 = ld32u(s.p + 8);
-        nq = 4;
         asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));      // waited for here: nothing is pending when the symbol loop is entered
     }
     __device__ __forceinline__ void to(Bits& s) const {
@@ -87,7 +85,6 @@ struct FastBits {
             bc += 32;
             q0 = q1; q1 = q2; q2 = q3;
             p += 4;
-            nq--;
         }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
@@ -387,9 +384,10 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
         // After a short match the loads of the copy are issued first, then the next symbol is decoded (bit buffer + LDS
         // only), and only then are the loaded bytes stored: the copy's round trip to L2 runs under the decoding.  The
         // eight loads are issued by every lane in every iteration (lanes without a deferred copy read the start of
-        // their member), together with the load of the next two input words: an iteration waits for memory ONCE, after
-        // the decode, for everything it and its predecessor issued (on gfx9 stores count in vmcnt like loads, so any
-        // earlier wait for a load would also be a wait for the acknowledgement of the stores before it).
+        // their member), together with the load of the next four input words: an iteration waits for memory ONCE — behind
+        // the decode AND the literal that may follow the symbol, ~150 instructions after the loads — for everything it and
+        // its predecessor issued (on gfx9 stores count in vmcnt like loads, so any earlier wait for a load would also be
+        // a wait for the acknowledgement of the stores before it).
         FastBits fb;
         fb.from(b);
         fb.refill();
@@ -400,6 +398,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             const uint8_t* dsrc = out;                      // (lanes without a deferred copy all read the same line: one tag lookup)
             uint8_t* ddst = obase;
             uint32_t need = 0;                              // bytes of a deferred copy (whole 8-byte steps)
+            uint32_t pat_d = 0;                             // its period, if it overlaps its own output (dist < 8)
             if (sym < 256) {
                 if (op >= isize) { bad = true; break; }
                 put((uint32_t)sym);
@@ -433,8 +432,11 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                 op += len;
                 const uint32_t whole = (len + 7u) & ~7u;
                 if (IRF_INFLATE_EXP & 1) {
-                } else if (may_overrun && whole <= 32u && dist >= whole) {
-                    if (!(IRF_INFLATE_EXP & 16)) { dsrc = src; ddst = dst; need = whole; }
+                } else if (may_overrun && whole <= 32u && (dist >= len || dist < 8u)) {
+                    // (dist >= len is enough: the loads may reach into the match's own, not yet written destination, but what
+                    //  they read there lands at offsets >= dist >= len, in the overrun.  dist < 8: the first 8 loaded bytes
+                    //  hold the period, the stored words are built from it below)
+                    if (!(IRF_INFLATE_EXP & 16)) { dsrc = src; ddst = dst; need = whole; pat_d = dist < len ? dist : 0u; }
                 } else if (IRF_INFLATE_EXP & 8) {
                 } else {
                     if (dist >= 8) {
@@ -493,24 +495,16 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
             const uint8_t* const hsrc = need > 16u ? dsrc + 16 : out;      // most matches are short: their upper half reads the shared line
 #pragma unroll
             for (int k = 0; k < 4; k++) w[4 + k] = (IRF_INFLATE_EXP & 1) ? 0u : ld32u(hsrc + 4 * k);
-            const bool reload = fb.nq < 2u + IRF_LITERAL_RUN;                // up to three refills until the next reload (the third: the literal pair below)
+            // every lane reloads its window (the 16 bytes at p) in every iteration; the loaded words are taken over BEHIND the
+            // literal step below, which still refills from the old window (it holds at least one word: an iteration starts
+            // with three or four and has taken at most two) — so the one wait of the iteration, for the window and the copy
+            // sources, comes a symbol later, when an L2 round trip is over.  A lane with a deferred copy has no pending
+            // literal bytes (flush_before_match), so the literal below stores nothing in front of the copy's stores.
+            static_assert(IRF_LITERAL_RUN <= 1, "the old window has one word left for the literal step");
             uint4 nw;
-            __builtin_memcpy(&nw, reload ? fb.p : in, 16);
+            __builtin_memcpy(&nw, fb.p, 16);
+            const uint8_t* const p_loaded = fb.p;
             sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
-            asm volatile("" ::"v"(nw.x), "v"(nw.y), "v"(nw.z), "v"(nw.w));      // the one wait: here, not at the next refill behind the stores below
-            fb.q0 = reload ? nw.x : fb.q0;
-            fb.q1 = reload ? nw.y : fb.q1;
-            fb.q2 = reload ? nw.z : fb.q2;
-            fb.q3 = reload ? nw.w : fb.q3;
-            fb.nq = reload ? 4u : fb.nq;
-            if (need) {
-                st32u(ddst, w[0]); st32u(ddst + 4, w[1]);
-                if (need > 8u) { st32u(ddst + 8, w[2]); st32u(ddst + 12, w[3]); }
-                if (need > 16u) { st32u(ddst + 16, w[4]); st32u(ddst + 20, w[5]); }
-                if (need > 24u) { st32u(ddst + 24, w[6]); st32u(ddst + 28, w[7]); }
-            }
-            // a literal needs nothing from memory: it is put at once and the symbol behind it decoded in the same
-            // iteration (the per-iteration costs — the wait, the loads every lane issues — are paid once for the pair)
 #pragma unroll
             for (int extra = 0; extra < IRF_LITERAL_RUN; extra++) {
                 if ((uint32_t)sym < 256u && op < isize) {
@@ -518,6 +512,34 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(const uint8_t* __r
                     fb.refill();
                     sym = decode_sym(s_tab, lane, lit, LIT_SYM, fb);
                 }
+            }
+            asm volatile("" ::"v"(nw.x), "v"(nw.y), "v"(nw.z), "v"(nw.w));      // the one wait
+            const bool shifted = fb.p != p_loaded;          // (by one word)
+            fb.q0 = shifted ? nw.y : nw.x;
+            fb.q1 = shifted ? nw.z : nw.y;
+            fb.q2 = shifted ? nw.w : nw.z;
+            fb.q3 = nw.w;
+            if (pat_d) {
+                // word j of the destination = the period starting at phase 8j mod dist
+                uint64_t pat = (uint64_t)w[0] | (uint64_t)w[1] << 32;
+                pat &= ~0ull >> (64u - 8u * pat_d);
+                for (uint32_t sh = pat_d; sh < 8; sh <<= 1) pat |= pat << (8u * sh);
+                const uint32_t r1 = (0x12302000u >> (4u * pat_d)) & 7u;        // 8 mod dist, dist = 1 .. 7
+                uint32_t r = 0;
+#pragma unroll
+                for (int j = 1; j < 4; j++) {
+                    r += r1;
+                    if (r >= pat_d) r -= pat_d;
+                    const uint64_t pj = r ? (pat >> (8u * r)) | (pat << (8u * (pat_d - r))) : pat;
+                    w[2 * j] = (uint32_t)pj; w[2 * j + 1] = (uint32_t)(pj >> 32);
+                }
+                w[0] = (uint32_t)pat; w[1] = (uint32_t)(pat >> 32);
+            }
+            if (need) {
+                st32u(ddst, w[0]); st32u(ddst + 4, w[1]);
+                if (need > 8u) { st32u(ddst + 8, w[2]); st32u(ddst + 12, w[3]); }
+                if (need > 16u) { st32u(ddst + 16, w[4]); st32u(ddst + 20, w[5]); }
+                if (need > 24u) { st32u(ddst + 24, w[6]); st32u(ddst + 28, w[7]); }
             }
         }
         fb.to(b);

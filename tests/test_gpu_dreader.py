@@ -97,6 +97,29 @@ def test_inflate_matches_zlib_on_every_block_type():
     assert engine.gpu_bgzf_inflate(b"").size == 0 and engine.gpu_bgzf_inflate(BGZF_EOF).size == 0
 
 
+def test_inflate_short_overlapping_matches_of_every_period():
+    """Matches that overlap their own output (distance < length): runs of every period 1 .. 9 and every length up to 40,
+    between random bytes — the deferred copy stores periods below 8 as a register pattern (all four 8-byte words, every
+    phase), 8 and above go through the in-place copy."""
+    rng = np.random.default_rng(11)
+    parts, want = [], []
+    for rep in range(4):
+        buf = bytearray()
+        for period in range(1, 10):
+            for total in range(period + 3, 41):
+                unit = bytes(rng.integers(0, 256, period, dtype=np.uint8).tolist())
+                buf += (unit * (total // period + 1))[:total]
+                buf += bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tolist())
+        data = bytes(buf[:65000])
+        for level, strat in ((6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED)):
+            parts.append(member(data, level, strat))
+            want.append(data)
+    got = engine.gpu_bgzf_inflate(b"".join(parts))
+    exp = np.frombuffer(b"".join(want), np.uint8)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp), int(np.argmax(got != exp))
+
+
 def test_inflate_refuses_corrupt_members():
     rng = np.random.default_rng(2)
     data = bytes(rng.integers(65, 70, 30000, dtype=np.uint8).tolist())
