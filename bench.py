@@ -624,7 +624,7 @@ def main():
             "from_page_locked_input": {"pairs_per_s": round(n_dec / best_pinned[0], 1), "h2d_ms": round(best_pinned[1], 3),
                                        "note": "same feed with the compressed bytes in page-locked host memory (DMA instead of a staged copy)"},
             "note": "irf_dreader_*: one feed of the whole file from pageable host memory (pairs_per_s includes the H2D copy and the "
-                    "host's member scan); inflate is one lane per BGZF member and takes ~22-25 ms for any number of members up to "
+                    "host's member scan); inflate is one lane per BGZF member and takes ~21-23 ms for any number of members up to "
                     "~40 k (irf_dreader_member_slots = 49 k), so the rate is proportional to the members per feed; "
                     "several 1 GB feeds with irf_dreader_set_pipeline: 82 M pairs/s (profiles/r01i_dreader_16m_pipeline.json)"}
         extra["h2d"] = {"bytes": int(in_bytes), "seconds": round(h2d_s, 4), "note": "pageable numpy -> device via torch (set-up, not timed)"}
