@@ -31,8 +31,18 @@ if shuffle:
     cols = {n: getattr(Batch(**cols).select(np.random.default_rng(7).permutation(len(cols["frag_chr"]))), n) for n in names}
 n_frag, n_blk = len(cols["frag_chr"]), len(cols["blk_start"])
 dev = torch.device("cuda:0")
-dten = {n: torch.from_numpy(cols[n]).to(dev) for n in names}
-db = engine.device_batch(dten, n_frag, n_blk)
+n_batches = int(os.environ.get("IRF_BENCH_BATCHES", "1"))         # the sample submitted as this many batches (consecutive fragments)
+dbs, keep = [], []
+if n_batches == 1:
+    parts = [cols]
+else:
+    whole = Batch(**cols)
+    edges = np.linspace(0, n_frag, n_batches + 1).astype(np.int64)
+    parts = [{n: getattr(whole.select(np.arange(edges[i], edges[i + 1])), n) for n in names} for i in range(n_batches)]
+for part in parts:
+    dten = {n: torch.from_numpy(part[n]).to(dev) for n in names}
+    keep.append(dten)
+    dbs.append(engine.device_batch(dten, len(part["frag_chr"]), len(part["blk_start"])))
 ref = engine.RefTables.from_texts(ann.ref_texts(hide_sj_frac=0.1, hide_seed=20240808))
 e = engine.Engine(ref)
 e.chr_map_update(ann.chr_names, ann.chr_lens)
@@ -41,7 +51,10 @@ if shuffle:
 ms, wall = [], []
 for r in range(reps):
     e.sync(); t0 = time.perf_counter()
-    e.reset(); e.submit(db); e.finalize(); e.sync()
+    e.reset()
+    for db in dbs:
+        e.submit(db)
+    e.finalize(); e.sync()
     wall.append((time.perf_counter() - t0) * 1e3)
     t = e.timing()
     ms.append(t["count_ms"])
@@ -52,5 +65,5 @@ for r in range(reps):
 res = e.results()
 chk = (int(res["chr_cnt"].sum()), int(res["sp_cnt"].astype(np.uint64).sum()), int(res["junc_cnt"].astype(np.uint64).sum()), int(res["roi_cnt"].sum()),
        float(np.nansum(res["nondir"]["intron_depth"])))
-print("lib=%s%s count_ms min %.3f all %s stats_ms %.3f step wall ms min %.3f check %s" % (os.path.basename(engine.LIB_PATH), " shuffled+ORDER_ANY" if shuffle else "", min(ms),
+print("lib=%s%s%s count_ms min %.3f all %s stats_ms %.3f step wall ms min %.3f check %s" % (os.path.basename(engine.LIB_PATH), " shuffled+ORDER_ANY" if shuffle else "", " %d batches" % n_batches if n_batches > 1 else "", min(ms),
       ["%.3f" % m for m in ms], t["stats_ms"], min(wall), chk), flush=True)
