@@ -172,6 +172,7 @@ struct Lds {
     // the slice's chunks: window origin of each, first block of each (and of the chunk behind the last); read once per slice
     unsigned long long s_org[kSlice];
     uint32_t s_kb[kSlice + 1];
+    uint32_t next_slice;               // the slice this workgroup takes next (from the queue)
 };
 
 // Inclusive sums with DPP row shifts / broadcasts: lane 15 of every 16-lane row ends up with the row's total
@@ -485,6 +486,7 @@ __device__ __forceinline__ void flush_novel(const CountTables& T, Lds& S, uint32
 __global__ __launch_bounds__(256) void chunk_origin_kernel(CountTables T, BatchDev B, uint32_t n_chunks) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= n_chunks) return;
+    if (c == 0u) T.chunk_origin[n_chunks] = 0ull;            // the count kernel's slice queue (behind the last chunk's origin)
     const uint32_t f = c * kChunk;
     unsigned long long o = kNoWin;
     const uint32_t chr = B.frag_chr[f], fs = B.frag_start[f];
@@ -556,7 +558,17 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
         }
         return r;
     };
+#ifdef K_STATIC_SLICES
     for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+#else
+    // Slices cost what their locus costs (blocks per fragment, events outside the window): a workgroup takes its first
+    // slice by its index and every further one from a queue (one returning atomic per slice, issued when the slice begins
+    // and looked at under its first chunk), so that no workgroup is left with the expensive ones at the end of the launch.
+    AS1 uint32_t* const slice_queue = (AS1 uint32_t*)(gp(T.chunk_origin) + n_chunks);
+    for (uint32_t slice = blockIdx.x; slice < n_slices; slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.next_slice)) {
+        uint32_t queued = 0;
+        if (tid == 0) queued = gridDim.x + __hip_atomic_fetch_add(slice_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         const uint32_t c0 = slice * kSlice;
         const uint32_t nc = n_chunks - c0 < kSlice ? n_chunks - c0 : kSlice;
         FragCols fc_next = load_frag(c0);
@@ -698,6 +710,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void count_kernel(const Co
             CPROF(1);
             // ---------------- the flush: every load above has landed, nothing is waited for until the barrier ----------------
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef K_STATIC_SLICES
+            if (tid == 0 && i == 0u) S.next_slice = queued;         // (read when the slice is over: many barriers from here)
+#endif
             flush_window(T, S, win_old, flush_to, lane, wave, s_cstat_local);
             for (uint32_t e = tid; e < n_oq; e += kThreads) oq_apply(T, S.oq[(i + 1u) & 1u][e]);
             CSTAT(3, wave == 0u ? n_oq : 0u); CSTAT(6, wave == 0u ? 1u : 0u);

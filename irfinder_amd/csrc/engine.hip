@@ -689,7 +689,7 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
             if (n_cu < 1) n_cu = 1;
-            const uint32_t wgs_per_cu[2] = {(uint32_t)env_u64("IRF_STATS_WGS_BIG", 6), (uint32_t)env_u64("IRF_STATS_WGS_SMALL", 24)};
+            const uint32_t wgs_per_cu[2] = {(uint32_t)env_u64("IRF_STATS_WGS_BIG", 6), (uint32_t)env_u64("IRF_STATS_WGS_SMALL", 192)};
             std::vector<uint32_t> members[2];
             for (uint32_t i = 0; i < n_intron; i++)
                 if (ref.in_measured[i] >= (1ull << 28)) return fail(IRF_E_RANGE, "an intron of ref-cover.bed has 2^28 or more measured bases");
@@ -938,7 +938,7 @@ int irf_ctx::submit(const irf_batch* b, uint64_t* id) {
     if (input_order == IRF_ORDER_ANY && B.n_frag > 1024u) TRY(reorder(B));       // (a batch of a few chunks has nothing to gain)
     {
         // (grown on the stream's own time line: a kernel of an earlier batch may still read the old array)
-        const size_t need = (size_t)B.n_frag / dev::count_chunk_fragments() + 1;
+        const size_t need = (size_t)B.n_frag / dev::count_chunk_fragments() + 2;      // (+ the slice queue word behind the last chunk)
         if (need > d_chunk_origin.cap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (d_chunk_origin.reserve(need + need / 4) != hipSuccess) return fail(IRF_E_NOMEM, "hipMalloc of the chunk table failed");

@@ -99,7 +99,8 @@ struct CountTables {
     unsigned long long* junc_count;
     uint32_t* err_flags;
     // [fragments of the batch / count_chunk_fragments(), rounded up] where the count kernel puts the window of every chunk
-    // (written by a kernel of launch_count in front of the count kernel)
+    // (written by a kernel of launch_count in front of the count kernel); one more word behind them: the queue the
+    // kernel's workgroups take their slices from, zeroed by the same kernel
     unsigned long long* chunk_origin;
     // known_junction_depth_kernel only: the plane map, the sorted keys (global_left << 28 | span), their rows and strands
     // (1 '-', 2 '+', 0/3 unknown) and the two vote sums of JunctionCount::Directional
