@@ -19,7 +19,8 @@
 //
 // Shape of the kernel (round 3).  The input is CSR (fragments -> blocks).  A workgroup takes SLICES of the (coordinate-sorted)
 // batch, kSlice chunks of kFPL x kThreads consecutive fragments each, and keeps its LDS accumulators across the chunks of a
-// slice.  Per chunk, between two workgroup barriers each:
+// slice; its first slice by its index, every further one from a queue (slices differ in cost).  Per chunk, between two
+// workgroup barriers each:
 //   F. fragment phase, kFPL fragments per lane: the chromosome record (a copy of the table in LDS), FragmentsInChr,
 //      FragmentsInROI; the fragment's facts (coordinate base, strand, chromosome length) go to LDS and the lane writes its
 //      id over the OWNER entries of its blocks (with a first / last flag).  Then, with every load of the phase landed, the
