@@ -75,7 +75,7 @@ __device__ unsigned long long g_cstat[8];
 #define K_FPL 1
 #endif
 #ifndef K_WIN
-#define K_WIN 2048
+#define K_WIN 4096
 #endif
 #ifndef K_LINES
 #define K_LINES 128
