@@ -700,7 +700,12 @@ int irf_ctx::build_map(uint32_t n, const char* const* names, const uint32_t* len
             for (int c = 0; c < 2; c++) {
                 auto& m = members[c];
                 std::stable_sort(m.begin(), m.end(), [&](uint32_t a, uint32_t b) { return ref.in_measured[a] > ref.in_measured[b]; });
-                uint32_t n_wg = std::min<uint64_t>((uint64_t)n_cu * std::max(wgs_per_cu[c], 1u), m.size());
+                // many short lists for the hardware to deal out (the one-wave class: 192 per CU), but about four introns per
+                // list at least — a list's first intron pays for the start of the header pipeline (a shard of a reference
+                // split over several GPUs has fewer introns than lists) — and never fewer lists than fill the device
+                const uint64_t most = (uint64_t)n_cu * std::max(wgs_per_cu[c], 1u);
+                const uint64_t fill = std::min<uint64_t>(most, (uint64_t)n_cu * (c == 0 ? 6u : 24u));
+                uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(most, std::max<uint64_t>(m.size() / 4, fill)), m.size());
                 stats_classes.n_wg[c] = n_wg;
                 std::vector<std::vector<uint32_t>> lists(n_wg);
                 typedef std::pair<uint64_t, uint32_t> Load;          // (cost so far, workgroup)
