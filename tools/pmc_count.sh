@@ -1,5 +1,6 @@
 #!/bin/bash
-# Diagnostic: hardware counters of the count kernel (separate rocprofv3 --pmc passes).  usage: tools/pmc_count.sh <outdir-under-gpurun_out>
+# Diagnostic: hardware counters of the count kernel (separate rocprofv3 --pmc passes).  usage: [IRF_PMC_PASSES=n] tools/pmc_count.sh <outdir-under-gpurun_out>
+# (IRF_PMC_PASSES=2: the two SQ passes only)
 out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -10,6 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_A
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_CYCLES" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TA_TA_BUSY_sum TA_FLAT_ATOMIC_WAVEFRONTS_sum"; do
   i=$((i+1))
+  [ $i -gt ${IRF_PMC_PASSES:-5} ] && break
   timeout -s KILL 150 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/tools/count_bench.py 50000000 3 > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; exit 1; }
 done
 python3 - $out <<'P'
